@@ -1,0 +1,151 @@
+// binning.hip -- (tile, Gaussian) pair emission, per-tile list ranges, render launch order.
+//
+// Pair emission follows reference CR/rasterizer_impl.cu:70-111 (duplicateWithKeys): every visible
+// Gaussian emits one pair per tile of its rectangle, rows outer / columns inner.  Differences in
+// structure (results identical after the sort, see sort.hip):
+//   - Gaussians are visited in depth order, the key is just the tile id (u32);
+//   - emission is wave-cooperative: a wave owns 64 consecutive Gaussians, and its lanes write the
+//     wave's whole contiguous output range 64 slots at a time (coalesced 4-B stores) instead of one
+//     thread writing a 10..40-slot run on its own.
+// Tile ranges follow reference CR/rasterizer_impl.cu:116-138 (identifyTileRanges) + the memset at :310.
+#include "common.hpp"
+
+namespace gsr {
+
+__global__ __launch_bounds__(256) void k_duplicate(int P, const uint32_t* __restrict__ order,
+                                                   const uint32_t* __restrict__ dup_offset,
+                                                   const uint32_t* __restrict__ tiles_touched,
+                                                   const uint2* __restrict__ rect, uint32_t gridx,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_off[4][64];
+    __shared__ uint32_t s_id[4][64];
+    __shared__ uint2 s_rect[4][64];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 256 + threadIdx.x;  // position in depth order
+
+    uint32_t off = 0, cnt = 0, id = 0;
+    uint2 rc = make_uint2(0, 0);
+    if (slot < P) {
+        id = order[slot];
+        off = dup_offset[slot];
+        cnt = tiles_touched[id];
+        rc = rect[id];
+    }
+    // lanes past P replicate the end offset so the search below never selects them
+    const uint32_t wave_begin = __shfl(off, 0, 64);
+    uint32_t last_valid_end = off + cnt;
+    {   // end of the wave's output range = max over lanes of off+cnt among valid lanes
+        uint32_t e = slot < P ? off + cnt : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(e, d, 64);
+            e = e > o ? e : o;
+        }
+        last_valid_end = e;
+    }
+    if (!(slot < P)) off = last_valid_end;
+    s_off[w][lane] = off;
+    s_id[w][lane] = id;
+    s_rect[w][lane] = rc;
+    __builtin_amdgcn_wave_barrier();
+
+    for (uint32_t p = wave_begin + lane; p < last_valid_end; p += 64) {
+        // largest s with s_off[s] <= p  (offsets are non-decreasing; zero-count entries are skipped)
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t cand = lo + step;
+            if (cand < 64 && s_off[w][cand] <= p) lo = cand;
+        }
+        const uint2 r = s_rect[w][lo];
+        const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
+        const uint32_t width = maxx - minx;
+        const uint32_t t = p - s_off[w][lo];
+        const uint32_t row = t / width, col = t - row * width;
+        keys[p] = (miny + row) * gridx + (minx + col);
+        vals[p] = s_id[w][lo];
+    }
+}
+
+int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
+                     uint32_t* vals)
+{
+    hipLaunchKernelGGL(k_duplicate, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
+                       g.tiles_touched, g.rect, (uint32_t)gridx, keys, vals);
+    return check_launch(L, "duplicate");
+}
+
+__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R) return;
+    const uint32_t cur = keys[idx];
+    if (idx == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = keys[idx - 1];
+        if (cur != prev) {
+            ranges[prev].y = (uint32_t)idx;
+            ranges[cur].x = (uint32_t)idx;
+        }
+    }
+    if (idx == R - 1) ranges[cur].y = (uint32_t)R;
+}
+
+int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T)
+{
+    if (hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), L.stream) != hipSuccess) return GSR_ERR_HIP;
+    if (R > 0) {
+        hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R, sorted_keys, ranges);
+        return check_launch(L, "tile_ranges");
+    }
+    return GSR_OK;
+}
+
+// ---- render launch order: tiles by descending list length (coarse: 32 log2 buckets) ----------------
+// Per-tile work is list length x 256 pixels and the spread is 5-10x; dispatching the
+// long lists first keeps the tail of the render kernel short.  Any permutation is correct.
+__device__ __forceinline__ uint32_t len_bucket(uint2 r)
+{
+    const uint32_t len = r.y - r.x;
+    return len == 0 ? 31u : (uint32_t)__builtin_clz(len);  // long lists -> small bucket id
+}
+
+__global__ __launch_bounds__(256) void k_order_hist(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ hist)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) atomicAdd(&hist[len_bucket(ranges[t])], 1u);
+}
+
+__global__ __launch_bounds__(64) void k_order_scan(uint32_t* __restrict__ hist)
+{
+    // 32 buckets: exclusive scan in one wave; hist[32+b] becomes the running cursor of bucket b
+    const uint32_t lane = threadIdx.x;
+    uint32_t v = lane < 32 ? hist[lane] : 0u, inc = v;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t n = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += n;
+    }
+    if (lane < 32) hist[32 + lane] = inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_order_fill(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ hist,
+                                                    uint32_t* __restrict__ tile_order)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) tile_order[atomicAdd(&hist[32 + len_bucket(ranges[t])], 1u)] = (uint32_t)t;
+}
+
+int launch_tile_order(const Launch& L, const ImageView& iv, int T)
+{
+    if (hipMemsetAsync(iv.order_hist, 0, 64 * sizeof(uint32_t), L.stream) != hipSuccess) return GSR_ERR_HIP;
+    const int nb = (T + 255) / 256;
+    hipLaunchKernelGGL(k_order_hist, dim3(nb), dim3(256), 0, L.stream, T, iv.ranges, iv.order_hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, L.stream, iv.order_hist);
+    hipLaunchKernelGGL(k_order_fill, dim3(nb), dim3(256), 0, L.stream, T, iv.ranges, iv.order_hist, iv.tile_order);
+    return check_launch(L, "tile_order");
+}
+
+}  // namespace gsr

@@ -1,0 +1,211 @@
+// preprocess.hip -- per-Gaussian forward stage: near-plane cull, clip-space projection, 3D->2D (EWA)
+// covariance projection with 0.3 px^2 dilation, conic, 3-sigma radius, tile rectangle, SH->RGB.
+//
+// Behaviour follows reference CR/forward.cu:158-259 (preprocessCUDA) + CR/auxiliary.h:41-56,139-164
+// (ndc2Pix, getRect, in_frustum).  Layout is ours: one thread per Gaussian, inputs are the caller's
+// AoS tensors read as contiguous 12/16/24-B runs per lane, the outputs the render kernels need are
+// packed into one 48-B Splat record per Gaussian (three coalesced 16-B stores per lane) and the
+// sort key (depth bits) is emitted directly, so nothing is re-read before the depth sort.
+#include "common.hpp"
+#include "splat_math.hpp"
+
+namespace gsr {
+
+// SH -> RGB, reference CR/forward.cu:20-71.  `sh` points at this Gaussian's first coefficient
+// (stride M rows of 3 floats; only (deg+1)^2 rows are read).
+__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t* clamp_mask)
+{
+    V3 dir = pos - campos;
+    const float len = sqrtf(dot3(dir, dir));
+    dir = v3(dir.x / len, dir.y / len, dir.z / len);
+#define SHV(k) v3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
+    V3 result = kSH_C0 * SHV(0);
+    if (deg > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        result = ((result - (kSH_C1 * y) * SHV(1)) + (kSH_C1 * z) * SHV(2)) - (kSH_C1 * x) * SHV(3);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            result = result + (kSH_C2[0] * xy) * SHV(4);
+            result = result + (kSH_C2[1] * yz) * SHV(5);
+            result = result + (kSH_C2[2] * (2.0f * zz - xx - yy)) * SHV(6);
+            result = result + (kSH_C2[3] * xz) * SHV(7);
+            result = result + (kSH_C2[4] * (xx - yy)) * SHV(8);
+            if (deg > 2) {
+                result = result + (kSH_C3[0] * y * (3.0f * xx - yy)) * SHV(9);
+                result = result + (kSH_C3[1] * xy * z) * SHV(10);
+                result = result + (kSH_C3[2] * y * (4.0f * zz - xx - yy)) * SHV(11);
+                result = result + (kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * SHV(12);
+                result = result + (kSH_C3[4] * x * (4.0f * zz - xx - yy)) * SHV(13);
+                result = result + (kSH_C3[5] * z * (xx - yy)) * SHV(14);
+                result = result + (kSH_C3[6] * x * (xx - 3.0f * yy)) * SHV(15);
+            }
+        }
+    }
+#undef SHV
+    result.x += 0.5f;
+    result.y += 0.5f;
+    result.z += 0.5f;
+    *clamp_mask = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
+    return v3(fmax_(result.x, 0.0f), fmax_(result.y, 0.0f), fmax_(result.z, 0.0f));
+}
+
+// (v+1)*S-1)/2 evaluated in double, rounded once (reference CR/auxiliary.h:41-44)
+__device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+__device__ __forceinline__ uint32_t clamp_tile(float f, uint32_t grid)
+{
+    int v = (int)f;  // truncation toward zero, as the C cast in getRect
+    v = v > 0 ? v : 0;
+    return grid < (uint32_t)v ? grid : (uint32_t)v;
+}
+
+struct PreArgs {
+    int P, D, M, W, H;
+    float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    int prefiltered, need_backward;
+    uint32_t gridx, gridy;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *view, *proj, *campos;
+    Splat* splat;
+    uint32_t* tiles_touched;
+    uint2* rect;
+    uint8_t* clamped;
+    uint32_t* dkey;
+    int* radii;
+    uint64_t* counters;
+};
+
+__global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+
+    // uniform data: 35 scalar loads, served by the scalar cache
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        view[i] = a.view[i];
+        proj[i] = a.proj[i];
+    }
+
+    int radius_out = 0;
+    uint32_t tiles = 0, key = 0xFFFFFFFFu, cmask = 0;
+    uint2 rect = make_uint2(0, 0);
+    Splat s;
+    s.q0 = make_float4(0, 0, 0, 0);
+    s.q1 = make_float4(0, 0, 0, 0);
+    s.q2 = make_float4(0, 0, 0, 0);
+
+    const V3 p_orig = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const V3 p_view = xform_point_4x3(p_orig, view);
+
+    if (p_view.z <= 0.2f) {
+        if (a.prefiltered) a.counters[1] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
+    } else {
+        const float hx = ((proj[0] * p_orig.x + proj[4] * p_orig.y) + proj[8] * p_orig.z) + proj[12];
+        const float hy = ((proj[1] * p_orig.x + proj[5] * p_orig.y) + proj[9] * p_orig.z) + proj[13];
+        const float hw = ((proj[3] * p_orig.x + proj[7] * p_orig.y) + proj[11] * p_orig.z) + proj[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float proj_x = hx * p_w, proj_y = hy * p_w;
+
+        float cov6[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            const V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            const float4 q = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+            cov3d_from_scale_rot(sc, a.scale_modifier, q, cov6, nullptr);
+        }
+
+        const Cov2D c = cov2d_project(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, cov6, view);
+        const float cov_x = c.cov.m[0][0] + 0.3f;  // dilation is ON in this fork (CR/forward.cu:112-113)
+        const float cov_y = c.cov.m[0][1];
+        const float cov_z = c.cov.m[1][1] + 0.3f;
+
+        const float det = (cov_x * cov_z - cov_y * cov_y);
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conic_x = cov_z * det_inv, conic_y = -cov_y * det_inv, conic_z = cov_x * det_inv;
+
+            const float mid = 0.5f * (cov_x + cov_z);
+            const float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+            const float px = ndc_to_pix(proj_x, a.W), py = ndc_to_pix(proj_y, a.H);
+
+            // getRect (CR/auxiliary.h:46-56); max_radius is an int there
+            const float r = (float)(int)my_radius;
+            const uint32_t minx = clamp_tile((px - r) / (float)TILE_X, a.gridx);
+            const uint32_t miny = clamp_tile((py - r) / (float)TILE_Y, a.gridy);
+            const uint32_t maxx = clamp_tile((((px + r) + (float)TILE_X) - 1.0f) / (float)TILE_X, a.gridx);
+            const uint32_t maxy = clamp_tile((((py + r) + (float)TILE_Y) - 1.0f) / (float)TILE_Y, a.gridy);
+            const uint32_t ntiles = (maxx - minx) * (maxy - miny);
+            if (ntiles != 0) {
+                V3 rgb;
+                if (a.colors_precomp) {
+                    rgb = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+                } else {
+                    const V3 cam = v3(a.campos[0], a.campos[1], a.campos[2]);
+                    rgb = sh_to_rgb(a.D, p_orig, cam, a.shs + (size_t)idx * a.M * 3, &cmask);
+                }
+                radius_out = (int)my_radius;
+                tiles = ntiles;
+                key = __float_as_uint(p_view.z);
+                rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
+                s.q0 = make_float4(px, py, conic_x, conic_y);
+                s.q1 = make_float4(conic_z, a.opacities[idx], rgb.x, rgb.y);
+                s.q2 = make_float4(rgb.z, p_view.z, 0.f, 0.f);
+            }
+        }
+    }
+
+    a.radii[idx] = radius_out;
+    a.tiles_touched[idx] = tiles;
+    a.dkey[idx] = key;
+    a.rect[idx] = rect;
+    a.splat[idx] = s;
+    if (a.need_backward) a.clamped[idx] = (uint8_t)cmask;
+}
+
+int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, int* radii)
+{
+    PreArgs a;
+    a.P = p.P; a.D = p.D; a.M = p.M; a.W = p.W; a.H = p.H;
+    a.tanfovx = p.tanfovx; a.tanfovy = p.tanfovy;
+    a.focal_y = p.H / (2.0f * p.tanfovy);  // reference CR/rasterizer_impl.cu:222-223
+    a.focal_x = p.W / (2.0f * p.tanfovx);
+    a.scale_modifier = p.scale_modifier;
+    a.prefiltered = p.prefiltered;
+    a.need_backward = p.need_backward;
+    a.gridx = (uint32_t)((p.W + TILE_X - 1) / TILE_X);
+    a.gridy = (uint32_t)((p.H + TILE_Y - 1) / TILE_Y);
+    a.means3D = p.means3D; a.shs = p.shs; a.colors_precomp = p.colors_precomp; a.opacities = p.opacities;
+    a.scales = p.scales; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
+    a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
+    a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.rect = g.rect; a.clamped = g.clamped;
+    a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters;
+    const int blocks = (p.P + 255) / 256;
+    hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(256), 0, L.stream, a);
+    return check_launch(L, "preprocess");
+}
+
+// reference CR/rasterizer_impl.cu:54-66 (checkFrustum): only the near-plane test is live
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const V3 p = v3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float z = ((view[2] * p.x + view[6] * p.y) + view[10] * p.z) + view[14];
+    present[idx] = !(z <= 0.2f);
+}
+
+int launch_mark_visible(const Launch& L, int P, const float* means3D, const float* view, uint8_t* present)
+{
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, means3D, view, present);
+    return check_launch(L, "mark_visible");
+}
+
+}  // namespace gsr

@@ -1,0 +1,191 @@
+"""diff_gaussian_rasterization -- MI355X-native drop-in for the reference package of the same name.
+
+Public surface mirrors /root/reference/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py
+field-for-field so the reference's callers (simple_raw_render.py:12,98-111,263-277) run unchanged on
+PyTorch-ROCm:
+
+    GaussianRasterizationSettings   NamedTuple, 12 fields, same order        (__init__.py:157-169)
+    GaussianRasterizer(nn.Module)   .forward(means3D, means2D, opacities, shs=, colors_precomp=, scales=,
+                                    rotations=, cov3D_precomp=) -> (color[3,H,W], radii[P]); .markVisible
+                                                                                                (:171-220)
+    rasterize_gaussians, _RasterizeGaussians (autograd Function, 9 inputs, grads in input order) (:21-155)
+    cpu_deep_copy_tuple                                                                         (:17-19)
+
+Underneath, ``_native`` (ctypes over the C-ABI HIP library, include/gsr.h) takes the place of the pybind
+module ``_C``.  No CPU path exists: tensors must live on a HIP device.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _native as _C
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def rasterize_gaussians(
+    means3D,
+    means2D,
+    sh,
+    colors_precomp,
+    opacities,
+    scales,
+    rotations,
+    cov3Ds_precomp,
+    raster_settings,
+):
+    return _RasterizeGaussians.apply(
+        means3D,
+        means2D,
+        sh,
+        colors_precomp,
+        opacities,
+        scales,
+        rotations,
+        cov3Ds_precomp,
+        raster_settings,
+    )
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        # argument order of the native call = reference __init__.py:60-80
+        args = (
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
+        )
+        need_backward = any(ctx.needs_input_grad)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
+                    *args, need_backward=need_backward)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
+                *args, need_backward=need_backward)
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.opacity_shape = tuple(opacities.shape)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+
+        # argument order of the native call = reference __init__.py:109-129
+        args = (
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+            geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug,
+        )
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+
+        # absent optionals were passed as empty tensors; their gradient slot gets None instead of a
+        # [P,...] tensor of the wrong shape (autograd validates shapes on ROCm torch 2.x)
+        def fit(g, inp):
+            return g if inp.numel() != 0 else None
+
+        grads = (
+            grad_means3D,
+            grad_means2D,
+            fit(grad_sh, sh),
+            fit(grad_colors_precomp, colors_precomp),
+            grad_opacities.reshape(ctx.opacity_shape),
+            fit(grad_scales, scales),
+            fit(grad_rotations, rotations),
+            fit(grad_cov3Ds_precomp, cov3Ds_precomp),
+            None,
+        )
+        return grads
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(
+            means3D,
+            means2D,
+            shs,
+            colors_precomp,
+            opacities,
+            scales,
+            rotations,
+            cov3D_precomp,
+            raster_settings,
+        )

@@ -1,0 +1,137 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native Gaussian tile rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of huzi96/gaussian-pcloud-render:
+ * the differentiable rasterizer behind diff_gaussian_rasterization.GaussianRasterizer.
+ * It replaces the reference's torch/pybind binding + CUDA core:
+ *
+ *   reference (under /root/reference/diff-gaussian-rasterization/)      this header
+ *   ------------------------------------------------------------------  -------------------------
+ *   ext.cpp:16  rasterize_gaussians        -> rasterize_points.cu:35   gsr_forward_stage1 + _stage2
+ *               CudaRasterizer::Rasterizer::forward  rasterizer.h:35-59
+ *   ext.cpp:17  rasterize_gaussians_backward -> rasterize_points.cu:117 gsr_backward
+ *               CudaRasterizer::Rasterizer::backward rasterizer.h:61-90
+ *   ext.cpp:18  mark_visible               -> rasterize_points.cu:198  gsr_mark_visible
+ *               CudaRasterizer::Rasterizer::markVisible rasterizer.h:28-33
+ *   rasterizer_impl.h:65-72 required<GeometryState/ImageState/BinningState>()
+ *                                                                       gsr_geom_bytes / gsr_image_bytes / gsr_binning_bytes
+ *   auxiliary.h:166-173 CHECK_CUDA(..., debug) + thrown runtime_error   int status + gsr_last_error()
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats; no torch / ATen / pybind types.
+ *   - the CALLER owns every buffer (inputs, outputs, the three opaque scratch arenas); the library
+ *     never allocates device memory on the hot path.  Arena contents are private to the library
+ *     (struct-of-arrays) and only need to survive from forward to backward, exactly
+ *     like geomBuffer/binningBuffer/imgBuffer in diff_gaussian_rasterization/__init__.py:97.
+ *   - optional inputs are NULL when absent (the reference passes data_ptr() of empty tensors, i.e.
+ *     nullptr: rasterizer_impl.cu:321,389,411).
+ *   - every launch goes to the explicit `stream` (the reference uses the legacy default stream).
+ *   - the binning arena size depends on num_rendered, which is only known after preprocess + scan,
+ *     hence two forward stages (the reference grows its arena through a std::function callback after
+ *     the same device->host read-back, rasterizer_impl.cu:279-285).
+ *   - return value: 0 = ok, negative = error (text via gsr_last_error()).  With debug != 0 the
+ *     library synchronises and checks after every kernel like CHECK_CUDA(…, true).
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_INVALID (-1)  /* bad argument (message says which)                              */
+#define GSR_ERR_HIP (-2)      /* a HIP call or kernel failed                                    */
+#define GSR_ERR_CAPACITY (-3) /* an arena is smaller than gsr_*_bytes() requires                */
+#define GSR_ERR_TRAP (-4)     /* prefiltered=1 but a point was culled (auxiliary.h:156-160)     */
+
+typedef void* gsr_stream_t; /* hipStream_t */
+
+/* Arguments shared by forward and backward: the 19/21-argument lists of
+ * diff_gaussian_rasterization/__init__.py:60-80,109-129 minus the tensors' metadata. */
+typedef struct gsr_params {
+    int P;                 /* number of Gaussians (means3D.size(0))                                  */
+    int D;                 /* active SH degree (raster_settings.sh_degree)                           */
+    int M;                 /* SH coefficients per Gaussian = sh.size(1), 0 when shs is absent        */
+    int W, H;              /* image_width, image_height                                              */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int prefiltered;
+    int debug;
+    int need_backward;     /* 0: inference call, skip the saves only backward reads (clamped mask)   */
+    const float* bg;             /* [3]        device */
+    const float* means3D;        /* [P,3]      device */
+    const float* shs;            /* [P,M,3]    device or NULL */
+    const float* colors_precomp; /* [P,3]      device or NULL */
+    const float* opacities;      /* [P]        device */
+    const float* scales;         /* [P,3]      device or NULL */
+    const float* rotations;      /* [P,4]      device or NULL */
+    const float* cov3D_precomp;  /* [P,6]      device or NULL */
+    const float* viewmatrix;     /* [16] column-major when flattened (auxiliary.h:58-76) device */
+    const float* projmatrix;     /* [16]       device */
+    const float* campos;         /* [3]        device */
+} gsr_params;
+
+/* Scratch arena sizes in bytes (256-B aligned sub-arrays inside). */
+size_t gsr_geom_bytes(int P);
+size_t gsr_image_bytes(int W, int H);
+size_t gsr_binning_bytes(int64_t num_rendered);
+
+/* Forward, stage 1: per-Gaussian preprocess (cull, EWA projection, SH colour), depth ordering of the
+ * Gaussians, prefix sum of touched-tile counts.  Writes radii[P]; returns num_rendered through
+ * *num_rendered_out after one 8-byte device->host read-back on `stream` (the only host sync of a
+ * frame, cf. rasterizer_impl.cu:281).  out_color is not touched. */
+int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
+                       int* radii, int64_t* num_rendered_out, gsr_stream_t stream);
+
+/* Forward, stage 2: (tile, Gaussian) pair emission in depth order, stable radix sort by tile, tile
+ * ranges, per-tile front-to-back alpha compositing.  Writes out_color[3,H,W] (planar CHW). */
+int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+                       void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
+
+/* Backward.  All dL_* outputs must be zero-filled by the caller (rasterize_points.cu:151-159);
+ * shapes: dL_dmean2D[P,3] dL_dconic[P,2,2] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3]
+ * dL_dcov3D[P,6] dL_dsh[P,M,3] dL_dscale[P,3] dL_drot[P,4]. */
+int gsr_backward(const gsr_params* p, const int* radii, int64_t num_rendered, const void* geom, size_t geom_bytes,
+                 const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
+                 const float* dL_dpix /* [3,H,W] */, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                 float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                 float* dL_drot, gsr_stream_t stream);
+
+/* present[i] = (view-space z of means3D[i] > 0.2)   (rasterizer_impl.cu:54-66) */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, gsr_stream_t stream);
+
+/* Inspection of the private arenas, for parity tests and the roofline report only (device->device
+ * copies into caller buffers; not part of the hot path).  `what` is one of GSR_Q_*. */
+#define GSR_Q_DEPTHS 1         /* float  [P]    view-space z of visible Gaussians (0 otherwise)            */
+#define GSR_Q_MEANS2D 2        /* float  [P,2]                                                              */
+#define GSR_Q_CONIC_OPACITY 3  /* float  [P,4]                                                              */
+#define GSR_Q_RGB 4            /* float  [P,3]                                                              */
+#define GSR_Q_TILES_TOUCHED 5  /* uint32 [P]                                                                */
+#define GSR_Q_POINT_LIST 6     /* uint32 [R]   Gaussian ids sorted by (tile, depth bits, id)                */
+#define GSR_Q_POINT_LIST_KEYS 7/* uint64 [R]   (tile<<32)|depth bits, rebuilt for comparison with CUB keys  */
+#define GSR_Q_RANGES 8         /* uint32 [T,2]                                                              */
+#define GSR_Q_FINAL_T 9        /* float  [H*W]                                                              */
+#define GSR_Q_N_CONTRIB 10     /* uint32 [H*W]                                                              */
+#define GSR_Q_TILE_NEED 12     /* uint32 [T]   list entries the tile's render actually walked (roofline model)    */
+#define GSR_Q_CLAMPED 11       /* uint8  [P,3]                                                              */
+int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, const void* image,
+              int64_t num_rendered, void* dst, size_t dst_bytes, gsr_stream_t stream);
+
+/* Per-kernel timing of the last calls on this thread (ms, hipEvent on `stream`), filled only when
+ * gsr_set_profiling(1) was called.  names/ms hold up to `cap` entries; returns the count and
+ * resets the record. */
+void gsr_set_profiling(int on);
+int gsr_get_profile(const char** names, float* ms, int cap);
+
+const char* gsr_last_error(void);
+const char* gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

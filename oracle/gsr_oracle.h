@@ -1,0 +1,115 @@
+/*
+ * gsr_oracle.h -- CPU restatement of the reference Gaussian tile rasterizer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path
+ * (gaussian-pcloud-render_amd/) may include, link or load this.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / reported CPU baseline.
+ *
+ * Every function restates one piece of
+ *   /root/reference/diff-gaussian-rasterization/cuda_rasterizer/
+ * (abbreviated CR/ below) in plain C, evaluated in IEEE fp32 in the source's
+ * operation order with no FMA contraction (built with -ffp-contract=off).
+ *
+ * Parity pin: see oracle/README.md.  Summary: checked (a) on the GPU box against
+ * oracle/_ref (the reference's own .cu sources built for gfx950 through
+ * hipify-perl, recipe oracle/build_ref.sh), (b) here against golden vectors
+ * produced by that reference build (tests/golden/ref_*.npz), (c) against the
+ * reference's Python SH evaluator models/sh_utils.py::eval_sh and its camera
+ * fixture validate/temp_state_dict.pt (tests/golden/py_*.npz).
+ */
+#ifndef GSR_ORACLE_H
+#define GSR_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Inputs of CudaRasterizer::Rasterizer::forward (CR/rasterizer.h:35-59). Optional
+ * pointers are NULL when absent (rasterize_points.cu passes data_ptr of empty
+ * tensors, which is nullptr). */
+typedef struct {
+    int P, D, M, W, H;
+    float tanfovx, tanfovy, scale_modifier;
+    int prefiltered;
+    const float *bg;            /* [3] */
+    const float *means3D;       /* [P,3] */
+    const float *shs;           /* [P,M,3] or NULL */
+    const float *colors_precomp;/* [P,3] or NULL */
+    const float *opacities;     /* [P] */
+    const float *scales;        /* [P,3] or NULL */
+    const float *rotations;     /* [P,4] or NULL */
+    const float *cov3D_precomp; /* [P,6] or NULL */
+    const float *viewmatrix;    /* [16] column-major */
+    const float *projmatrix;    /* [16] column-major */
+    const float *campos;        /* [3] */
+} orc_inputs;
+
+/* Everything the forward produces, including the reference's private arenas
+ * (GeometryState / BinningState / ImageState, CR/rasterizer_impl.h:32-62). */
+typedef struct {
+    int P, W, H, gridx, gridy;
+    int64_t R;                   /* num_rendered */
+    /* GeometryState */
+    float    *depths;            /* [P]   */
+    uint8_t  *clamped;           /* [P,3] */
+    int32_t  *radii;             /* [P]   */
+    float    *means2D;           /* [P,2] */
+    float    *cov3D;             /* [P,6] */
+    float    *conic_opacity;     /* [P,4] */
+    float    *rgb;               /* [P,3] */
+    uint32_t *tiles_touched;     /* [P]   */
+    uint32_t *point_offsets;     /* [P] inclusive scan */
+    /* BinningState */
+    uint64_t *keys_unsorted;     /* [R] */
+    uint32_t *vals_unsorted;     /* [R] */
+    uint64_t *keys;              /* [R] sorted */
+    uint32_t *vals;              /* [R] sorted = point_list */
+    /* ImageState */
+    uint32_t *ranges;            /* [T,2] */
+    float    *final_T;           /* [H*W] accum_alpha */
+    uint32_t *n_contrib;         /* [H*W] */
+    /* output */
+    float    *out_color;         /* [3,H,W] */
+    /* instrumentation for the algorithmic-bytes model */
+    int64_t  visible;            /* #radii>0 */
+    int64_t  consumed_fwd;       /* C  = sum over tiles of entries needed before the last pixel stops */
+    int64_t  consumed_bwd;       /* C' = sum over tiles of max_pixel n_contrib */
+} orc_state;
+
+/* Full forward, K1..K4 of CR/rasterizer_impl.cu:198-336.  nthreads<=1 -> serial. */
+orc_state *orc_forward(const orc_inputs *in, int nthreads);
+void orc_free(orc_state *st);
+
+/* Full backward, CR/rasterizer_impl.cu:340-434.  Gradient buffers must be
+ * zero-filled by the caller (rasterize_points.cu:151-159 does torch::zeros).
+ * Pixel->Gaussian sums (the reference's float atomicAdd, order undefined) are
+ * accumulated in double and rounded once: the order-independent value. */
+void orc_backward(const orc_inputs *in, const orc_state *st, const float *dL_dpix,
+                  float *dL_dmean2D /*[P,3]*/, float *dL_dconic /*[P,4]*/, float *dL_dopacity /*[P]*/,
+                  float *dL_dcolor /*[P,3]*/, float *dL_dmean3D /*[P,3]*/, float *dL_dcov3D /*[P,6]*/,
+                  float *dL_dsh /*[P,M,3]*/, float *dL_dscale /*[P,3]*/, float *dL_drot /*[P,4]*/,
+                  int nthreads);
+
+/* CR/rasterizer_impl.cu:54-66,141-153 */
+void orc_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                      uint8_t *present);
+
+/* Stage-level entry points (used by tests that feed one stage's inputs directly). */
+uint32_t orc_get_higher_msb(uint32_t n);                                    /* CR/rasterizer_impl.cu:35-50 */
+void orc_inclusive_scan_u32(int64_t n, const uint32_t *in, uint32_t *out);  /* cub::DeviceScan::InclusiveSum */
+void orc_sort_pairs(int64_t n, const uint64_t *kin, const uint32_t *vin,
+                    uint64_t *kout, uint32_t *vout, int end_bit);           /* cub::DeviceRadixSort::SortPairs(…,0,end_bit) */
+void orc_identify_tile_ranges(int64_t L, const uint64_t *keys, uint32_t *ranges); /* CR/rasterizer_impl.cu:116-138 */
+
+/* SH colour of one Gaussian (CR/forward.cu:20-71); exposed for the eval_sh pin. */
+void orc_sh_to_rgb(int deg, int max_coeffs, const float *mean, const float *campos, const float *sh,
+                   float *rgb_out, uint8_t *clamped_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

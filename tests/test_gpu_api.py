@@ -1,0 +1,141 @@
+"""GPU tests of the drop-in Python surface (GaussianRasterizer / GaussianRasterizationSettings) used the way
+the reference caller uses it (simple_raw_render.py:227-288): settings per view, means2D dummy leaf, keyword call,
+autograd backward.  Results are checked against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import build_scene, seeded_dL
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(s, dev, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    # as the reference caller passes them: [1,4,4] non-contiguous views of transposed matrices, campos [1,1,3]
+    view = torch.from_numpy(s.viewmatrix.reshape(4, 4).T.copy()).to(dev).t().unsqueeze(0)
+    proj = torch.from_numpy(s.projmatrix.reshape(4, 4).T.copy()).to(dev).t().unsqueeze(0)
+    assert not view[0].is_contiguous()
+    return GaussianRasterizationSettings(
+        image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=torch.from_numpy(s.bg).to(dev),
+        scale_modifier=s.scale_modifier, viewmatrix=view, projmatrix=proj, sh_degree=s.sh_degree,
+        campos=torch.from_numpy(s.campos).to(dev).reshape(1, 1, 3), prefiltered=False, debug=debug)
+
+
+def _leaf(a, dev):
+    return torch.from_numpy(a).to(dev).requires_grad_(True)
+
+
+@pytest.mark.parametrize("name", ["random_aniso", "capsule_circle", "big_splats"])
+def test_module_forward_backward_matches_oracle(name, oracle, gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    s = build_scene(name)
+    dev = gpu_device
+    means3D, shs = _leaf(s.means3D, dev), _leaf(s.shs, dev)
+    opac, scales, rots = _leaf(s.opacities.reshape(-1, 1), dev), _leaf(s.scales, dev), _leaf(s.rotations, dev)
+    means2D = torch.zeros_like(means3D, dtype=torch.float32, requires_grad=True, device="cuda") + 0
+    means2D.retain_grad()
+    rasterizer = GaussianRasterizer(_settings(s, dev))
+    img, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opac,
+                            scales=scales, rotations=rots, cov3D_precomp=None)
+    assert img.shape == (3, s.H, s.W) and radii.shape == (s.P,) and radii.dtype == torch.int32
+    dL = seeded_dL(s)
+    (img * torch.from_numpy(dL).to(dev)).sum().backward()
+
+    o, go = oracle.forward_backward(s, dL)
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    err = np.abs(img.detach().cpu().numpy() - o["out_color"]).max(axis=0)
+    assert (err > 1e-4).mean() <= 2e-3
+    pairs = [(means3D.grad, "dL_dmean3D"), (means2D.grad, "dL_dmean2D"), (shs.grad, "dL_dsh"), (opac.grad, "dL_dopacity"),
+             (scales.grad, "dL_dscale"), (rots.grad, "dL_drot")]
+    for g, k in pairs:
+        a, b = g.cpu().numpy().reshape(-1).astype(np.float64), go[k].reshape(-1).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-30, k
+
+
+def test_colors_precomp_and_cov3d_paths(oracle, gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = gpu_device
+    s = build_scene("colors_precomp")
+    colors = _leaf(s.colors_precomp, dev)
+    means3D = _leaf(s.means3D, dev)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    img, _ = GaussianRasterizer(_settings(s, dev))(
+        means3D=means3D, means2D=means2D, colors_precomp=colors, opacities=torch.from_numpy(s.opacities).to(dev).reshape(-1, 1),
+        scales=torch.from_numpy(s.scales).to(dev), rotations=torch.from_numpy(s.rotations).to(dev))
+    dL = seeded_dL(s)
+    (img * torch.from_numpy(dL).to(dev)).sum().backward()
+    o, go = oracle.forward_backward(s, dL)
+    assert np.abs(img.detach().cpu().numpy() - o["out_color"]).max() <= 1e-4
+    a, b = colors.grad.cpu().numpy().astype(np.float64), go["dL_dcolor"].astype(np.float64)
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+
+    s = build_scene("cov3d_precomp")
+    cov = _leaf(s.cov3D_precomp, dev)
+    means3D = _leaf(s.means3D, dev)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    img, _ = GaussianRasterizer(_settings(s, dev))(
+        means3D=means3D, means2D=means2D, shs=torch.from_numpy(s.shs).to(dev), opacities=torch.from_numpy(s.opacities).to(dev).reshape(-1, 1),
+        cov3D_precomp=cov)
+    dL = seeded_dL(s)
+    (img * torch.from_numpy(dL).to(dev)).sum().backward()
+    o, go = oracle.forward_backward(s, dL)
+    assert np.abs(img.detach().cpu().numpy() - o["out_color"]).max() <= 1e-4
+    a, b = cov.grad.cpu().numpy().astype(np.float64), go["dL_dcov3D"].astype(np.float64)
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+
+
+def test_no_grad_inference_call_and_empty_cloud(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = gpu_device
+    s = build_scene("one_gaussian")
+    with torch.no_grad():
+        means3D = torch.from_numpy(s.means3D).to(dev)
+        img, radii = GaussianRasterizer(_settings(s, dev))(
+            means3D=means3D, means2D=torch.zeros_like(means3D), shs=torch.from_numpy(s.shs).to(dev),
+            opacities=torch.from_numpy(s.opacities).to(dev).reshape(-1, 1), scales=torch.from_numpy(s.scales).to(dev),
+            rotations=torch.from_numpy(s.rotations).to(dev))
+    assert img.isfinite().all() and int(radii[0]) > 0
+    # P == 0: the reference returns an all-zero image, not the background (rasterize_points.cu:68,81)
+    e3 = torch.zeros((0, 3), device=dev)
+    img, radii = GaussianRasterizer(_settings(s, dev))(
+        means3D=e3, means2D=e3, colors_precomp=e3, opacities=torch.zeros((0, 1), device=dev),
+        scales=e3, rotations=torch.zeros((0, 4), device=dev))
+    assert img.shape == (3, s.H, s.W) and not img.any() and radii.numel() == 0
+
+
+def test_argument_validation_messages(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = gpu_device
+    s = build_scene("one_gaussian")
+    r = GaussianRasterizer(_settings(s, dev))
+    m = torch.from_numpy(s.means3D).to(dev)
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(means3D=m, means2D=m, opacities=m[:, :1])
+    with pytest.raises(Exception, match="Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!"):
+        r(means3D=m, means2D=m, opacities=m[:, :1], colors_precomp=m)
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        r(means3D=m.reshape(-1), means2D=m, opacities=m[:, :1], colors_precomp=m, scales=m, rotations=torch.zeros((1, 4), device=dev))
+
+
+def test_prefiltered_trap_and_debug_mode(gpu_device, tmp_path, monkeypatch):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = gpu_device
+    monkeypatch.chdir(tmp_path)
+    s = build_scene("culled_mix")
+    st = _settings(s, dev, debug=True)._replace(prefiltered=True)
+    m = torch.from_numpy(s.means3D).to(dev)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), shs=torch.from_numpy(s.shs).to(dev),
+                               opacities=torch.from_numpy(s.opacities).to(dev).reshape(-1, 1),
+                               scales=torch.from_numpy(s.scales).to(dev), rotations=torch.from_numpy(s.rotations).to(dev))
+    assert (tmp_path / "snapshot_fw.dump").exists()   # reference behaviour with debug=True (__init__.py:83-90)
+
+
+def test_determinism_of_forward(gpu_device):
+    s = build_scene("capsule_circle")
+    a, _ = util.run_product(s, gpu_device)
+    b, _ = util.run_product(s, gpu_device)
+    assert a["out_color"].tobytes() == b["out_color"].tobytes()
+    np.testing.assert_array_equal(a["vals"], b["vals"])

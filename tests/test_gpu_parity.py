@@ -1,0 +1,152 @@
+"""GPU parity tests (-m gpu): the HIP product, called through the C ABI, against
+  (1) the plain-C CPU oracle (oracle/gsr_oracle.c), and
+  (2) the reference's own kernels built for gfx950 (oracle/_ref, strict = no FMA contraction) when present.
+
+Bars (BASELINE.json north_star / SURVEY.md 8c):
+  * integer / index outputs -- radii, tiles touched, num_rendered, the sorted (key, value) list incl. tie order,
+    tile ranges, n_contrib -- bit-exact;
+  * per-Gaussian forward floats (means2D, depth, conic, rgb) bit-exact vs both (only IEEE +,-,*,/,sqrt involved);
+  * rendered RGB: bit-exact vs the reference build (same exp, same op order); vs the CPU oracle (glibc expf vs
+    ocml expf can differ in the last bit) max-abs <= 1e-4 on every pixel that is not a threshold flip, flips counted;
+  * gradients: max|d| <= 2e-4 * max|g| per tensor (float accumulation order differs by construction).
+"""
+import numpy as np
+import pytest
+
+import util
+from util import SCENES, build_scene, run_product, seeded_dL
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4          # north_star: "within 1e-4 max abs (fp32)"
+GRAD_REL_TOL = 2e-4     # of max|g| per gradient tensor
+MAX_FLIP_FRACTION = 2e-3
+
+
+def _ref(variant="strict"):
+    from oracle.oracle import Reference
+    if not Reference.available(variant):
+        pytest.skip("oracle/_ref/libgsr_ref_%s.so not built (needs /root/reference at build time)" % variant)
+    return Reference(variant)
+
+
+def _check_integers(p, o, tag):
+    assert p["R"] == o["R"], "%s: num_rendered %d != %d" % (tag, p["R"], o["R"])
+    np.testing.assert_array_equal(p["radii"], o["radii"], err_msg=tag + " radii")
+    if p["P"] == 0:
+        return
+    np.testing.assert_array_equal(p["tiles_touched"], o["tiles_touched"], err_msg=tag + " tiles_touched")
+    np.testing.assert_array_equal(p["vals"], o["vals"], err_msg=tag + " point_list (sorted values, tie order)")
+    np.testing.assert_array_equal(p["keys"], o["keys"], err_msg=tag + " sorted keys")
+    np.testing.assert_array_equal(p["ranges"], o["ranges"], err_msg=tag + " tile ranges")
+
+
+def _check_geom_floats_exact(p, o, tag):
+    vis = o["radii"] > 0
+    for k in ("means2D", "depths", "conic_opacity", "rgb"):
+        a, b = p[k][vis], o[k][vis]
+        assert a.tobytes() == b.tobytes(), "%s: %s differs (max ulp %d)" % (tag, k, util.ulp_diff(a, b).max())
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_forward_vs_oracle(name, oracle, gpu_device):
+    s = build_scene(name)
+    o = oracle.forward(s)
+    p, _ = run_product(s, gpu_device)
+    _check_integers(p, o, "oracle")
+    if s.P == 0:
+        return
+    _check_geom_floats_exact(p, o, "oracle")
+    # image: a pixel is a "flip" if the two exp implementations put some alpha / T on different sides of a
+    # threshold; everything else must agree to 1e-4
+    nc_diff = p["n_contrib"] != o["n_contrib"]
+    err = np.abs(p["out_color"] - o["out_color"]).max(axis=0)
+    flips = nc_diff | (err > RGB_TOL)
+    frac = flips.mean()
+    assert frac <= MAX_FLIP_FRACTION, "%s: %d threshold-flip pixels (%.2e of image)" % (name, flips.sum(), frac)
+    assert err[~flips].max(initial=0.0) <= RGB_TOL
+    np.testing.assert_allclose(p["final_T"][~flips], o["final_T"][~flips], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_forward_vs_reference_build_bit_exact(name, gpu_device):
+    ref = _ref("strict")
+    s = build_scene(name)
+    r = ref.forward(s)
+    p, _ = run_product(s, gpu_device)
+    _check_integers(p, r, "ref")
+    if s.P == 0:
+        assert not p["out_color"].any() and not r["out_color"].any()  # reference quirk: zero image, no background
+        return
+    _check_geom_floats_exact(p, r, "ref")
+    np.testing.assert_array_equal(p["n_contrib"], r["n_contrib"])
+    assert p["final_T"].tobytes() == r["final_T"].tobytes(), "final_T differs, max ulp %d" % util.ulp_diff(p["final_T"], r["final_T"]).max()
+    assert p["out_color"].tobytes() == r["out_color"].tobytes(), "out_color differs: max abs %g" % np.abs(p["out_color"] - r["out_color"]).max()
+
+
+def _check_grads(gp, go, tag, tol=GRAD_REL_TOL):
+    for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"):
+        a, b = gp[k].reshape(-1).astype(np.float64), go[k].reshape(-1).astype(np.float64)
+        assert a.shape == b.shape, (tag, k, gp[k].shape, go[k].shape)
+        if a.size == 0:
+            continue
+        assert np.isfinite(a).all(), "%s %s: non-finite gradient" % (tag, k)
+        scale = np.abs(b).max()
+        d = np.abs(a - b).max()
+        assert d <= tol * scale + 1e-30, "%s %s: max|d|=%g vs %g*max|g|=%g" % (tag, k, d, tol, tol * scale)
+
+
+BWD_SCENES = [n for n in SCENES if n not in ("all_culled",)]
+
+
+@pytest.mark.parametrize("name", BWD_SCENES)
+def test_backward_vs_oracle(name, oracle, gpu_device):
+    s = build_scene(name)
+    dL = seeded_dL(s)
+    o, go = oracle.forward_backward(s, dL)
+    p, gp = run_product(s, gpu_device, dL_dpix=dL)
+    # only compare gradients when the forward bookkeeping the backward replays is identical
+    if s.P and (p["n_contrib"] != o["n_contrib"]).any():
+        pytest.skip("forward threshold flip between glibc and ocml expf on this scene; covered vs the reference build")
+    if s.P:
+        np.testing.assert_array_equal(p["clamped"].astype(bool), o["clamped"].astype(bool))
+    _check_grads(gp, go, name)
+
+
+@pytest.mark.parametrize("name", BWD_SCENES)
+def test_backward_vs_reference_build(name, oracle, gpu_device):
+    ref = _ref("strict")
+    s = build_scene(name)
+    dL = seeded_dL(s)
+    _, gr = ref.forward_backward(s, dL)
+    _, gp = run_product(s, gpu_device, dL_dpix=dL)
+    gr = dict(gr)
+    gr["dL_dopacity"] = gr["dL_dopacity"].reshape(gp["dL_dopacity"].shape)
+    _check_grads(gp, gr, name + " (ref)")
+
+
+def test_mark_visible(oracle, gpu_device):
+    import torch
+    from diff_gaussian_rasterization import _native as N
+    s = build_scene("culled_mix")
+    want = oracle.mark_visible(s.means3D, s.viewmatrix, s.projmatrix)
+    got = N.mark_visible(torch.from_numpy(s.means3D).to(gpu_device), torch.from_numpy(s.viewmatrix.reshape(4, 4)).to(gpu_device),
+                         torch.from_numpy(s.projmatrix.reshape(4, 4)).to(gpu_device)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert 0 < want.sum() < want.size
+
+
+def test_fma_contraction_moves_few_decisions(gpu_device):
+    """Context for the parity claim: the reference built WITH hipcc's default FMA contraction (standing in for
+    nvcc -fmad=true) vs the strict source semantics the product follows.  Integer outputs must stay (almost)
+    identical; the count of moved decisions is printed for the record."""
+    strict, fast = _ref("strict"), _ref("fast")
+    s = build_scene("capsule_circle")
+    a, b = strict.forward(s), fast.forward(s)
+    moved_radii = int((a["radii"] != b["radii"]).sum())
+    moved_R = abs(a["R"] - b["R"])
+    err = np.abs(a["out_color"] - b["out_color"])
+    print("FMA contraction: radii moved %d / %d, |dR| = %d, out_color max abs %.3g, pixels > 1e-4: %d"
+          % (moved_radii, s.P, moved_R, err.max(), int((err.max(axis=0) > 1e-4).sum())))
+    assert moved_radii <= max(2, s.P // 5000)
+    assert (err.max(axis=0) > 1e-4).mean() < 5e-3
