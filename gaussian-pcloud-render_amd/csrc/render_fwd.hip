@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256) void k_render_forward(RenderArgs a)
 
     for (int base = 0; base < total; base += RB) {
         // workgroup-wide early exit (reference: __syncthreads_count(done) == BLOCK_SIZE)
+        const bool wave_live = !__all(done);  // ballot over the whole wave, taken in uniform control flow
         if (tid == 0) s_live = 0;
         __syncthreads();
-        if (lane == 0 && !__all(done)) s_live = 1;  // benign race: every writer stores 1
+        if (lane == 0 && wave_live) s_live = 1;  // benign race: every writer stores 1
         __syncthreads();
         if (!s_live) break;
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_render_forward(RenderArgs a)
         }
         __syncthreads();
 
-        if (!__all(done)) {
+        if (wave_live) {
             for (int j = 0; j < n; j++) {
                 const float4 q0 = s_q0[j];
                 const float2 q1 = s_q1[j];
