@@ -1,0 +1,217 @@
+"""bench.py -- frames/s of the rasterizer hot path (forward + backward) on the headline workload.
+
+    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json metric, configs[2]): synth-THuman-800K -- 800 000 synthetic Gaussians
+("training" profile: opacity U(0.2,1), SH degree 1 in 13 rows) rendered at 1920x1080 from the reference's 12
+`circle` cameras, forward + backward through the public GaussianRasterizer API, loss = sum(img * G).
+A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered on
+rank 0 with RCCL (weak scaling).  All inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 with the throughput plus
+  roofline     -- the dominant kernel's algorithmic bytes / its measured duration (hipEvents on the launch stream)
+  cpu_baseline -- the plain-C oracle (OpenMP, all host cores) timed on one frame of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "gaussian-pcloud-render_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+
+def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
+    """Minimum HBM bytes each step of the pipeline has to move (per frame).  Render / preprocess figures are
+    SURVEY.md 8(d)'s; the sort figures follow this library's own data flow (u32 keys, u32 ids)."""
+    b = {}
+    b["preprocess"] = (44 + 12 * K) * P + 75 * V + 8 * (P - V)
+    b["depth_sort"] = 4 * (4 + 8 + 8) * P
+    b["offsets_scan"] = 3 * 8 * P
+    b["duplicate"] = 20 * P + 8 * R
+    b["tile_sort"] = tile_passes * (4 + 8 + 8) * R
+    b["tile_ranges"] = 4 * R + 16 * T
+    b["render_forward"] = 40 * C_fwd + 8 * T + 20 * N
+    b["render_backward"] = 40 * C_bwd + 20 * N + 44 * V
+    b["preprocess_backward"] = 92 * V + (107 + 12 * K) * V + (40 + 12 * K) * V
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="synth-THuman-800K")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--points", type=int, default=None, help="override the point count (debug)")
+    ap.add_argument("--profile", default="training", choices=["training", "inference"])
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _native
+    from pcrender import camera, multiview, synth
+
+    W, H = args.width, args.height
+    cloud = synth.make_cloud(args.workload, seed=0, P=args.points)
+    g = synth.make_gaussians(cloud, profile=args.profile, seed=1)
+    P, M, D = g["means3D"].shape[0], g["shs"].shape[1], g["sh_degree"]
+    n_views = 12
+    views = camera.circle_views(n_imgs=n_views, fov_deg=45.0, width_px=W, height_px=H)
+    bg = torch.ones(3, device=dev)  # simple_benchmark.py:332 background (1,1,1)
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=v["tanfovx"], tanfovy=v["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=v["viewmatrix"].to(dev), projmatrix=v["projmatrix"].to(dev), sh_degree=D, campos=v["campos"].to(dev),
+        prefiltered=False, debug=False) for v in views]
+    rasterizers = [GaussianRasterizer(s) for s in settings]
+
+    grad = not args.forward_only
+    leaf = lambda a: torch.from_numpy(a).to(dev).requires_grad_(grad)  # noqa: E731
+    means3D, shs, opac = leaf(g["means3D"]), leaf(g["shs"]), leaf(g["opacities"])
+    scales, rots = leaf(g["scales"]), leaf(g["rotations"])
+    means2D = torch.zeros_like(means3D, requires_grad=grad)
+    leaves = [means3D, means2D, shs, opac, scales, rots]
+    G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
+    gather_list = [torch.empty((3, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(i):
+        v = (i * world + rank) % n_views
+        if grad:
+            img, _ = rasterizers[v](means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+            (img * G).sum().backward()
+            for t in leaves:
+                t.grad = None
+            img = img.detach()
+        else:
+            with torch.no_grad():
+                img, _ = rasterizers[v](means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales,
+                                        rotations=rots)
+        if world > 1 and not args.no_gather:
+            dist.gather(img, gather_list=gather_list, dst=0)
+        return v
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    _native.set_profiling(rank == 0)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _native.get_profile() if rank == 0 else []
+    _native.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- workload statistics for the bytes model, averaged over the views rank 0 rendered
+        used = sorted({((args.warmup + i) * world) % n_views for i in range(args.steps)})
+        stats = dict(V=0.0, R=0.0, C_fwd=0.0, C_bwd=0.0)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        with torch.no_grad():
+            for v in used:
+                s = settings[v]
+                R, _, radii, geom, binning, img = _native.rasterize_gaussians(
+                    s.bg, means3D, torch.empty(0), opac, scales, rots, 1.0, torch.empty(0), s.viewmatrix, s.projmatrix,
+                    s.tanfovx, s.tanfovy, H, W, shs, D, s.campos, False, False, need_backward=True)
+                need = _native.query("TILE_NEED", P, W, H, R, geom, binning, img).long()
+                nc = _native.query("N_CONTRIB", P, W, H, R, geom, binning, img).view(H, W)
+                ncp = torch.zeros((((H + 15) // 16) * 16, ((W + 15) // 16) * 16), dtype=nc.dtype, device=dev)
+                ncp[:H, :W] = nc
+                cb = ncp.view(ncp.shape[0] // 16, 16, ncp.shape[1] // 16, 16).amax(dim=(1, 3)).long().sum()
+                stats["V"] += float((radii > 0).sum()) / len(used)
+                stats["R"] += float(R) / len(used)
+                stats["C_fwd"] += float(need.sum()) / len(used)
+                stats["C_bwd"] += float(cb) / len(used)
+        tile_bits = int(T).bit_length()
+        bytes_per = algorithmic_bytes(P, stats["V"], stats["R"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
+                                      (tile_bits + 7) // 8)
+        ms = {}
+        for name, t in prof:
+            ms.setdefault(name, []).append(t)
+        avg_ms = {k: float(np.mean(v)) for k, v in ms.items()}
+        dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
+        roofline = None
+        if dom is not None:
+            achieved = bytes_per[dom] / (avg_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes": int(bytes_per[dom]), "avg_ms": round(avg_ms[dom], 4)}
+        frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
+        frame_gpu_ms = sum(avg_ms.values())
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.oracle import Oracle, Scene
+            orc = Oracle()
+            v0 = views[0]
+            sc = Scene(W=W, H=H, tanfovx=v0["tanfovx"], tanfovy=v0["tanfovy"], bg=np.ones(3, np.float32), means3D=g["means3D"],
+                       opacities=g["opacities"], viewmatrix=v0["viewmatrix"].numpy(), projmatrix=v0["projmatrix"].numpy(),
+                       campos=v0["campos"].numpy(), shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
+            cores = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            if grad:
+                orc.forward_backward(sc, G.cpu().numpy(), nthreads=cores)
+            else:
+                orc.forward(sc, nthreads=cores)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "sample": "1 frame (circle view 0) of the same workload, %s, plain-C oracle with OpenMP" %
+                             ("forward+backward" if grad else "forward")}
+
+        out = {
+            "metric": "rendered frames/sec at 1080p (fwd+bwd), THuman-800K" if (grad and (W, H) == (1920, 1080)) else
+                      "rendered frames/sec %dx%d (%s)" % (W, H, "fwd+bwd" if grad else "fwd"),
+            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d), view-sharded%s" % (
+                args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M,
+                " + RCCL frame gather" if world > 1 and not args.no_gather else ""),
+                "points": P, "num_rendered_avg": int(stats["R"]), "visible_avg": int(stats["V"]),
+                "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+            "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
+                          "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,10 +14,12 @@
 // largest n_contrib instead of the list end: entries no pixel of the tile consumed are never staged.
 // Summation order differs from the reference's (undefined) atomic order; results agree to fp32 rounding.
 #include "common.hpp"
+#include "tile_cull.hpp"
 
 namespace gsr {
 
 constexpr int BRB = 256;   // entries staged per round
+constexpr int BGRP = 4;    // entries evaluated per inner-loop trip (see render_fwd.hip for the latency rationale)
 constexpr int NACC = 9;    // mean2D.x,y  conic.x,y,w  opacity  colour r,g,b
 
 template <int CTRL, int ROW_MASK>
@@ -38,6 +40,12 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+struct BEntry {
+    float4 q0;   // x, y, conic.x, conic.y
+    float2 q1;   // conic.z, opacity
+    float4 col;  // r, g, b, -
+};
+
 struct RenderBwdArgs {
     const uint2* ranges;
     const uint32_t* tile_order;
@@ -56,11 +64,13 @@ struct RenderBwdArgs {
 
 __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
 {
-    __shared__ float4 s_q0[BRB];   // x, y, conic.x, conic.y
-    __shared__ float2 s_q1[BRB];   // conic.z, opacity
-    __shared__ float4 s_col[BRB];  // r, g, b, -
+    __shared__ float4 s_q0[BRB + 1];   // x, y, conic.x, conic.y   (slot BRB = null entry used for padding)
+    __shared__ float2 s_q1[BRB + 1];   // conic.z, opacity
+    __shared__ float4 s_col[BRB + 1];  // r, g, b, -
     __shared__ uint32_t s_id[BRB];
-    __shared__ float s_acc[BRB][NACC];
+    __shared__ float s_acc[BRB + 1][NACC];
+    __shared__ uint16_t s_list[4][BRB + 2 * BGRP];  // per quadrant: staged entries that may touch it (tile_cull.hpp)
+    __shared__ uint32_t s_cnt[4][4];
     __shared__ uint32_t s_max[4];
 
     const uint32_t tile = a.tile_order[blockIdx.x];
@@ -70,6 +80,8 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
     const uint32_t py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixf_x = (float)px, pixf_y = (float)py;
+    const float tile_px = (float)(tx * TILE_X), tile_py = (float)(ty * TILE_Y);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
 
     const uint2 range = a.ranges[tile];
@@ -111,9 +123,16 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
     const float ddelx_dx = (float)(0.5 * a.W);
     const float ddely_dy = (float)(0.5 * a.H);
 
+    if (tid == 0) {
+        s_q0[BRB] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: alpha = 0, never hits
+        s_q1[BRB] = make_float2(0.f, 0.f);
+        s_col[BRB] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     for (int base = 0; base < total; base += BRB) {
         const int n = total - base < BRB ? total - base : BRB;
         __syncthreads();  // previous round's flush is finished before LDS is reused
+        uint32_t qmask = 0;
         if ((int)tid < n) {
             const uint32_t id = a.point_list[range.x + (uint32_t)(total - 1 - base - (int)tid)];
             const Splat* sp = a.splat + id;
@@ -122,61 +141,117 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
             s_q0[tid] = q0;
             s_q1[tid] = make_float2(q1.x, q1.y);
             s_col[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
+            qmask = quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_px, tile_py);
         }
-        for (int i = tid; i < BRB * NACC; i += 256) (&s_acc[0][0])[i] = 0.f;
+        for (int i = tid; i < (BRB + 1) * NACC; i += 256) (&s_acc[0][0])[i] = 0.f;
+        uint64_t bal[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bal[q] = __ballot((qmask >> q) & 1u);
+            if (lane == 0) s_cnt[q][w] = (uint32_t)__popcll(bal[q]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t off = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ww++)
+                if ((uint32_t)ww < w) off += s_cnt[q][ww];
+            if ((qmask >> q) & 1u) s_list[q][off + (uint32_t)__popcll(bal[q] & lt_mask)] = (uint16_t)tid;
+        }
+        const int nq = (int)(s_cnt[w][0] + s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3]);
+        const int nq_pad = (nq + BGRP - 1) / BGRP * BGRP;
+        if ((int)lane < nq_pad + BGRP - nq) s_list[w][nq + lane] = (uint16_t)BRB;
         __syncthreads();
 
-        for (int j = 0; j < n; j++) {
-            const uint32_t f = (uint32_t)(total - 1 - base - j);  // 0-based index from the list front
-            const float4 q0 = s_q0[j];
-            const float2 q1 = s_q1[j];
-            const float dx = q0.x - pixf_x, dy = q0.y - pixf_y;
-            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, q1.y * G);
-            const bool hit = (f < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (!__any(hit)) continue;
-
-            float g[NACC];
+        const uint16_t* lst = s_list[w];
+        BEntry cur[BGRP], nxt[BGRP];
+        uint32_t ci[BGRP], ni[BGRP];
 #pragma unroll
-            for (int k = 0; k < NACC; k++) g[k] = 0.f;
-            if (hit) {
-                const float4 col = s_col[j];
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0;
-                lc0 = col.x;
-                dL_dalpha += (col.x - acc_r0) * dpx0;
-                acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1;
-                lc1 = col.y;
-                dL_dalpha += (col.y - acc_r1) * dpx1;
-                acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2;
-                lc2 = col.z;
-                dL_dalpha += (col.z - acc_r2) * dpx2;
-                g[6] = dchannel_dcolor * dpx0;
-                g[7] = dchannel_dcolor * dpx1;
-                g[8] = dchannel_dcolor * dpx2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-
-                const float dL_dG = q1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-                const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-                g[0] = dL_dG * dG_ddelx * ddelx_dx;
-                g[1] = dL_dG * dG_ddely * ddely_dy;
-                g[2] = -0.5f * gdx * dx * dL_dG;
-                g[3] = -0.5f * gdx * dy * dL_dG;
-                g[4] = -0.5f * gdy * dy * dL_dG;
-                g[5] = G * dL_dalpha;
+        for (int k = 0; k < BGRP; k++) {
+            ci[k] = lst[k];
+            cur[k].q0 = s_q0[ci[k]];
+            cur[k].q1 = s_q1[ci[k]];
+            cur[k].col = s_col[ci[k]];
+        }
+        for (int j0 = 0; j0 < nq_pad; j0 += BGRP) {
+#pragma unroll
+            for (int k = 0; k < BGRP; k++) {
+                ni[k] = lst[j0 + BGRP + k];
+                nxt[k].q0 = s_q0[ni[k]];
+                nxt[k].q1 = s_q1[ni[k]];
+                nxt[k].col = s_col[ni[k]];
+            }
+            float dxs[BGRP], dys[BGRP], Gs[BGRP], alphas[BGRP];
+            bool hits[BGRP];
+            bool any_lane_hit = false;
+#pragma unroll
+            for (int k = 0; k < BGRP; k++) {
+                // 0-based index of this entry from the list front; the null entry (slot BRB) wraps to a huge value
+                const uint32_t f = (uint32_t)(total - 1 - base) - ci[k];
+                const float dx = cur[k].q0.x - pixf_x, dy = cur[k].q0.y - pixf_y;
+                const float power = -0.5f * (cur[k].q0.z * dx * dx + cur[k].q1.x * dy * dy) - cur[k].q0.w * dx * dy;
+                const float G = expf(power);
+                const float alpha = fminf(0.99f, cur[k].q1.y * G);
+                dxs[k] = dx; dys[k] = dy; Gs[k] = G; alphas[k] = alpha;
+                hits[k] = (f < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                any_lane_hit = any_lane_hit || hits[k];
+            }
+            if (__any(any_lane_hit)) {
+#pragma unroll
+                for (int k = 0; k < BGRP; k++) {
+                    if (!__any(hits[k])) continue;  // wave-uniform
+                    const bool hit = hits[k];
+                    const float alpha = alphas[k], dx = dxs[k], dy = dys[k];
+                    const float4 col = cur[k].col;
+                    const float4 q0 = cur[k].q0;
+                    const float2 q1 = cur[k].q1;
+                    // The reference's two divisions by (1 - alpha) share one reciprocal here (gradients are compared
+                    // to tolerance, not bit-for-bit: the accumulation order differs anyway).
+                    const float rcp = 1.0f / (1.f - alpha);
+                    const float Tn = T * rcp;
+                    const float r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0;
+                    const float r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1;
+                    const float r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2;
+                    float dL_dalpha = (col.x - r0) * dpx0;
+                    dL_dalpha += (col.y - r1) * dpx1;
+                    dL_dalpha += (col.z - r2) * dpx2;
+                    dL_dalpha *= Tn;
+                    dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
+                    // lanes that do not hit contribute exact zeros: three selects zero every product below
+                    const float dLa = hit ? dL_dalpha : 0.f;
+                    const float G = hit ? Gs[k] : 0.f;
+                    const float dch = hit ? alpha * Tn : 0.f;
+                    const float dL_dG = q1.y * dLa;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+                    const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+                    float g[NACC];
+                    g[0] = dL_dG * dG_ddelx * ddelx_dx;
+                    g[1] = dL_dG * dG_ddely * ddely_dy;
+                    g[2] = -0.5f * gdx * dx * dL_dG;
+                    g[3] = -0.5f * gdx * dy * dL_dG;
+                    g[4] = -0.5f * gdy * dy * dL_dG;
+                    g[5] = G * dLa;
+                    g[6] = dch * dpx0;
+                    g[7] = dch * dpx1;
+                    g[8] = dch * dpx2;
+                    T = hit ? Tn : T;
+                    acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
+                    lc0 = hit ? col.x : lc0; lc1 = hit ? col.y : lc1; lc2 = hit ? col.z : lc2;
+                    last_alpha = hit ? alpha : last_alpha;
+#pragma unroll
+                    for (int c = 0; c < NACC; c++) g[c] = wave_sum_to_lane63(g[c]);
+                    if (lane == 63) {
+#pragma unroll
+                        for (int c = 0; c < NACC; c++) atomicAdd(&s_acc[ci[k]][c], g[c]);
+                    }
+                }
             }
 #pragma unroll
-            for (int k = 0; k < NACC; k++) g[k] = wave_sum_to_lane63(g[k]);
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < NACC; k++) atomicAdd(&s_acc[j][k], g[k]);
+            for (int k = 0; k < BGRP; k++) {
+                cur[k] = nxt[k];
+                ci[k] = ni[k];
             }
         }
         __syncthreads();
