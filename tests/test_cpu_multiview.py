@@ -1,0 +1,79 @@
+"""CPU tests of the N>1 path: view sharding + frame gather + gradient reduction with torch.distributed `gloo`,
+world_size 2 (and 3 for an uneven split), one process per rank, rendezvous on 127.0.0.1."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gaussian-pcloud-render_amd"))
+
+
+def _frame(v, H=6, W=10):
+    """Deterministic stand-in for a rendered frame of view v."""
+    g = torch.Generator().manual_seed(1000 + v)
+    return torch.rand((3, H, W), generator=g)
+
+
+def _worker(rank, world, port, n_views, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcrender import multiview
+    try:
+        out = multiview.render_views(_frame, n_views, dst=0)
+        grads = [torch.full((4, 3), float(rank + 1)), None, torch.arange(5, dtype=torch.float32) * (rank + 1)]
+        multiview.reduce_gradients(grads)
+        ok = True
+        if rank == 0:
+            want = torch.stack([_frame(v) for v in range(n_views)], 0)
+            ok = out is not None and out.shape == want.shape and torch.equal(out, want)
+        else:
+            ok = out is None
+        tot = world * (world + 1) / 2
+        ok = ok and torch.equal(grads[0], torch.full((4, 3), tot)) and grads[1] is None
+        ok = ok and torch.equal(grads[2], torch.arange(5, dtype=torch.float32) * tot)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n_views, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_shard_views_partition():
+    from pcrender import multiview
+    for n_views, world in [(12, 1), (12, 2), (12, 8), (8, 8), (12, 5)]:
+        parts = [multiview.shard_views(n_views, r, world) for r in range(world)]
+        assert sorted(v for p in parts for v in p) == list(range(n_views))
+        assert max(len(p) for p in parts) == multiview.max_shard(n_views, world)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_gather_world2_even():
+    _run(2, 12, 29631)
+
+
+def test_gather_world3_uneven_shards():
+    _run(3, 8, 29632)     # shards of 3,3,2 views: padded for the collective, trimmed on the root
+
+
+def test_single_process_passthrough():
+    from pcrender import multiview
+    out = multiview.render_views(_frame, 4)
+    assert out.shape == (4, 3, 6, 10) and torch.equal(out[2], _frame(2))
+    with pytest.raises(ValueError):
+        multiview.render_views(_frame, 0)

@@ -1,0 +1,31 @@
+"""CPU tests of the synthetic workload generator: determinism, shapes, statistics."""
+import numpy as np
+
+from pcrender import synth
+
+
+def test_clouds_are_deterministic_and_shaped():
+    a = synth.make_cloud("synth-THuman-256", seed=0, P=5000)
+    b = synth.make_cloud("synth-THuman-256", seed=0, P=5000)
+    assert a["means3D"].tobytes() == b["means3D"].tobytes() and a["means3D"].shape == (5000, 3)
+    # voxelised: coordinates sit on the 1/256 grid and are distinct (pcgc_rescale convention)
+    q = a["means3D"].astype(np.float64) * 256
+    assert np.abs(q - np.round(q)).max() < 1e-6 and np.unique(np.round(q), axis=0).shape[0] == 5000
+    c = synth.make_cloud("synth-THuman-800K", seed=0, P=4000)
+    assert c["scale_factor"] == 448.0 and c["means3D"].dtype == np.float32
+    assert -1.3 < c["means3D"][:, 1].min() < -1.0 and 0.95 < c["means3D"][:, 1].max() < 1.1   # ~2.2 units tall, y up
+    assert 0 <= c["rgb"].min() and c["rgb"].max() <= 1
+
+
+def test_gaussian_parameters_follow_the_reference_conventions():
+    c = synth.make_cloud("synth-THuman-800K", seed=0, P=3000)
+    g = synth.make_gaussians(c, profile="training", seed=1)
+    assert g["shs"].shape == (3000, 13, 3) and g["sh_degree"] == 1       # M=13 rows for degree 1 (quirk Q6)
+    assert not g["shs"][:, 4:].any() and g["shs"][:, 1:4].any()
+    np.testing.assert_allclose(g["shs"][:, 0], (c["rgb"] - 0.5) / synth.SH_C0, rtol=1e-5, atol=1e-6)
+    radius = np.sqrt(3) / 448.0 * 6
+    assert abs(np.median(g["scales"]) / radius - 1) < 0.05
+    assert g["opacities"].shape == (3000, 1) and 0.2 <= g["opacities"].min() and g["opacities"].max() <= 1.0
+    assert abs(np.linalg.norm(g["rotations"], axis=1).mean() - 1) < 0.05 and not np.allclose(np.linalg.norm(g["rotations"], axis=1), 1)
+    gi = synth.make_gaussians(c, profile="inference", seed=1)
+    assert (gi["opacities"] == 1).all() and not gi["shs"][:, 1:].any()
