@@ -192,7 +192,7 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
     {
         ProfScope ps("tile_ranges", L.stream);
         if (int e = launch_tile_ranges(L, R, b.key[res], iv.ranges, T)) return e;
-        if (int e = launch_tile_order(L, iv, T)) return e;
+        if (int e = launch_tile_order(L, iv, T, false)) return e;
     }
     {
         ProfScope ps("render_forward", L.stream);
@@ -221,6 +221,10 @@ int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* g
     const ImageView iv = image_view(align256(const_cast<void*>(image)), p->W, p->H);
     const int passes = (tile_bits(tile_count(p)) + RADIX_BITS - 1) / RADIX_BITS;
     const int res = R > 0 ? (passes & 1) : 0;
+    {
+        ProfScope ps("tile_order_bwd", L.stream);
+        if (int e = launch_tile_order(L, iv, tile_count(p), true)) return e;
+    }
     {
         ProfScope ps("render_backward", L.stream);
         if (int e = launch_render_backward(L, *p, g, b.val[res], iv, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor)) return e;
@@ -301,6 +305,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     case GSR_Q_FINAL_T: src = iv.final_T; bytes = (size_t)N * 4; break;
     case GSR_Q_N_CONTRIB: src = iv.n_contrib; bytes = (size_t)N * 4; break;
     case GSR_Q_TILE_NEED: src = iv.tile_need; bytes = (size_t)T * 4; break;
+    case GSR_Q_TILE_CLOCK: src = iv.tile_clock; bytes = (size_t)T * 32; break;
     default: return fail(GSR_ERR_INVALID, "[gsr] query: unknown item %d", what);
     }
     if (dst_bytes < bytes) return fail(GSR_ERR_CAPACITY, "[gsr] query %d: destination too small", what);

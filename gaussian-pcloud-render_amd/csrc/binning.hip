@@ -103,44 +103,79 @@ int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, 
     return GSR_OK;
 }
 
-// ---- render launch order: tiles by descending list length (coarse: 32 log2 buckets) ----------------
-// Per-tile work is list length x 256 pixels and the spread is 5-10x; dispatching the
-// long lists first keeps the tail of the render kernel short.  Any permutation is correct.
-__device__ __forceinline__ uint32_t len_bucket(uint2 r)
+// ---- render launch order: tiles by descending work estimate (128 quarter-octave buckets) -------------
+// Per-tile work is (entries walked) x 256 pixels and the spread is 5-10x; dispatching the
+// heavy tiles first keeps the tail of the render kernels short.  The forward pass only knows the list length;
+// the backward pass knows exactly how many entries each tile consumed (tile_need, written by the forward).
+// Any permutation is correct.
+constexpr int ORD_BUCKETS = 128;
+
+__device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 {
-    const uint32_t len = r.y - r.x;
-    return len == 0 ? 31u : (uint32_t)__builtin_clz(len);  // long lists -> small bucket id
+    if (len == 0) return ORD_BUCKETS - 1;
+    const uint32_t msb = 31u - (uint32_t)__builtin_clz(len);          // 0..31
+    const uint32_t frac = msb >= 2 ? (len >> (msb - 2)) & 3u : 0u;    // next two bits
+    const uint32_t rank = msb * 4u + frac;                            // larger = more work, 0..127
+    return (ORD_BUCKETS - 2) - (rank < ORD_BUCKETS - 2 ? rank : ORD_BUCKETS - 2);
 }
 
-// One 1024-thread workgroup: LDS histogram over the 32 length buckets, 32-lane scan, LDS cursors.
-// (T is 8 160 at 1080p, 32 400 at 4K; three passes over `ranges` out of L2 cost a few microseconds, and a single
-// workgroup avoids thousands of same-address global atomics from the empty tiles that all share one bucket.)
-__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order)
+// One 1024-thread workgroup: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
+// wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
+// one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
+__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ need,
+                                                     uint32_t* __restrict__ tile_order)
 {
-    __shared__ uint32_t cnt[32];
-    __shared__ uint32_t cur[32];
-    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    __shared__ uint32_t cnt[ORD_BUCKETS];
+    __shared__ uint32_t cur[ORD_BUCKETS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (threadIdx.x < ORD_BUCKETS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) atomicAdd(&cnt[len_bucket(ranges[t])], 1u);
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const uint32_t lane = threadIdx.x;
-        const uint32_t v = lane < 32 ? cnt[lane] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const uint32_t n = __shfl_up(inc, d, 64);
-            if (lane >= (uint32_t)d) inc += n;
+    const int T_pad = (T + 1023) / 1024 * 1024;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int t = threadIdx.x; t < T_pad; t += 1024) {
+            const bool ok = t < T;
+            uint32_t b = 0;
+            if (ok) b = work_bucket(need ? need[t] : ranges[t].y - ranges[t].x);
+            const bool empty = ok && b == ORD_BUCKETS - 1;
+            const uint64_t em = __ballot(empty);
+            uint32_t slot = 0;
+            if (pass == 0) {
+                if (empty) { if ((em & lt_mask) == 0) atomicAdd(&cnt[b], (uint32_t)__popcll(em)); }
+                else if (ok) atomicAdd(&cnt[b], 1u);
+            } else {
+                uint32_t basev = 0;
+                const int leader = em ? (int)__builtin_ctzll(em) : 0;
+                if (empty && (int)lane == leader) basev = atomicAdd(&cur[b], (uint32_t)__popcll(em));
+                basev = __shfl(basev, leader, 64);
+                if (empty) slot = basev + (uint32_t)__popcll(em & lt_mask);
+                else if (ok) slot = atomicAdd(&cur[b], 1u);
+                if (ok) tile_order[slot] = (uint32_t)t;
+            }
         }
-        if (lane < 32) cur[lane] = inc - v;
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x < 64) {   // exclusive scan of 128 counts by one wave, two per lane
+                const uint32_t a0 = cnt[2 * lane], a1 = cnt[2 * lane + 1];
+                uint32_t inc = a0 + a1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t n = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t)d) inc += n;
+                }
+                cur[2 * lane] = inc - a0 - a1;
+                cur[2 * lane + 1] = inc - a1;
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) tile_order[atomicAdd(&cur[len_bucket(ranges[t])], 1u)] = (uint32_t)t;
 }
 
-int launch_tile_order(const Launch& L, const ImageView& iv, int T)
+int launch_tile_order(const Launch& L, const ImageView& iv, int T, bool by_need)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, L.stream, T, iv.ranges, iv.tile_order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, L.stream, T, iv.ranges,
+                       by_need ? (const uint32_t*)iv.tile_need : (const uint32_t*)nullptr,
+                       by_need ? iv.tile_order_bwd : iv.tile_order);
     return check_launch(L, "tile_order");
 }
 

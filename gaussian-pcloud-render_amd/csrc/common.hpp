@@ -67,9 +67,10 @@ struct ImageView {
     uint2* ranges;        // [T]
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
-    uint32_t* tile_order; // [T] tiles sorted by descending list length (render launch order)
-    uint32_t* order_hist; // [64]
+    uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
+    uint32_t* tile_order_bwd; // [T] tiles by descending consumed entries (backward render launch order)
     uint32_t* tile_need;  // [T] entries walked by the forward render (instrumentation for the bytes model)
+    uint64_t* tile_clock; // [T,4] wall_clock64 (100 MHz) at start/end of the tile's forward and backward workgroup (debug)
     size_t bytes;
 };
 
@@ -130,8 +131,9 @@ inline ImageView image_view(void* base, int W, int H)
     carve(cur, v.final_T, N ? N : 1);
     carve(cur, v.n_contrib, N ? N : 1);
     carve(cur, v.tile_order, T ? T : 1);
-    carve(cur, v.order_hist, (size_t)64);
+    carve(cur, v.tile_order_bwd, T ? T : 1);
     carve(cur, v.tile_need, T ? T : 1);
+    carve(cur, v.tile_clock, 4 * (T ? T : 1));
     v.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return v;
 }
@@ -169,7 +171,7 @@ int launch_offsets_scan(const Launch& L, int P, const uint32_t* order, const uin
 int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
                      uint32_t* vals);
 int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T);
-int launch_tile_order(const Launch& L, const ImageView& iv, int T);
+int launch_tile_order(const Launch& L, const ImageView& iv, int T, bool by_need);
 // render_fwd.hip / render_bwd.hip
 int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
                           const ImageView& iv, float* out_color);

@@ -13,6 +13,8 @@
 // so global atomics drop from 9*256 to at most 9 per (tile, entry).  The walk also starts at the tile's
 // largest n_contrib instead of the list end: entries no pixel of the tile consumed are never staged.
 // Summation order differs from the reference's (undefined) atomic order; results agree to fp32 rounding.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -60,6 +62,7 @@ struct RenderBwdArgs {
     float* dL_dconic;    // [P,4]
     float* dL_dopacity;  // [P]
     float* dL_dcolor;    // [P,3]
+    uint64_t* tile_clock;
 };
 
 __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
     __shared__ uint32_t s_max[4];
 
     const uint32_t tile = a.tile_order[blockIdx.x];
+    const uint64_t clk0 = wall_clock64();
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
@@ -198,32 +202,47 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
                 any_lane_hit = any_lane_hit || hits[k];
             }
             if (__any(any_lane_hit)) {
+                // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.  Only T,
+                // accum_rec, last_color and last_alpha are serial; a lane that does not hit multiplies T by 1 and
+                // keeps its state (selects), so the four steps are a short dependent chain the scheduler can
+                // overlap with phase 2 of the same group.
+                float dLa[BGRP], Gh[BGRP], dch[BGRP];
 #pragma unroll
                 for (int k = 0; k < BGRP; k++) {
-                    if (!__any(hits[k])) continue;  // wave-uniform
                     const bool hit = hits[k];
-                    const float alpha = alphas[k], dx = dxs[k], dy = dys[k];
+                    const float alpha = alphas[k];
                     const float4 col = cur[k].col;
-                    const float4 q0 = cur[k].q0;
-                    const float2 q1 = cur[k].q1;
                     // The reference's two divisions by (1 - alpha) share one reciprocal here (gradients are compared
                     // to tolerance, not bit-for-bit: the accumulation order differs anyway).
                     const float rcp = 1.0f / (1.f - alpha);
-                    const float Tn = T * rcp;
-                    const float r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0;
-                    const float r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1;
-                    const float r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2;
+                    const float Tn = T * (hit ? rcp : 1.0f);
+                    const float om = 1.f - last_alpha;
+                    const float r0 = last_alpha * lc0 + om * acc_r0;
+                    const float r1 = last_alpha * lc1 + om * acc_r1;
+                    const float r2 = last_alpha * lc2 + om * acc_r2;
                     float dL_dalpha = (col.x - r0) * dpx0;
                     dL_dalpha += (col.y - r1) * dpx1;
                     dL_dalpha += (col.z - r2) * dpx2;
                     dL_dalpha *= Tn;
                     dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
-                    // lanes that do not hit contribute exact zeros: three selects zero every product below
-                    const float dLa = hit ? dL_dalpha : 0.f;
-                    const float G = hit ? Gs[k] : 0.f;
-                    const float dch = hit ? alpha * Tn : 0.f;
-                    const float dL_dG = q1.y * dLa;
-                    const float gdx = G * dx, gdy = G * dy;
+                    // lanes that do not hit contribute exact zeros: three selects zero every product of phase 2
+                    dLa[k] = hit ? dL_dalpha : 0.f;
+                    Gh[k] = hit ? Gs[k] : 0.f;
+                    dch[k] = hit ? alpha * Tn : 0.f;
+                    T = Tn;
+                    acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
+                    lc0 = hit ? col.x : lc0; lc1 = hit ? col.y : lc1; lc2 = hit ? col.z : lc2;
+                    last_alpha = hit ? alpha : last_alpha;
+                }
+                // Phase 2: per entry, the nine partial derivatives, wave reduction, LDS accumulation.
+#pragma unroll
+                for (int k = 0; k < BGRP; k++) {
+                    if (!__any(hits[k])) continue;  // wave-uniform
+                    const float dx = dxs[k], dy = dys[k];
+                    const float4 q0 = cur[k].q0;
+                    const float2 q1 = cur[k].q1;
+                    const float dL_dG = q1.y * dLa[k];
+                    const float gdx = Gh[k] * dx, gdy = Gh[k] * dy;
                     const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
                     const float dG_ddely = -gdy * q1.x - gdx * q0.w;
                     float g[NACC];
@@ -232,14 +251,10 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
                     g[2] = -0.5f * gdx * dx * dL_dG;
                     g[3] = -0.5f * gdx * dy * dL_dG;
                     g[4] = -0.5f * gdy * dy * dL_dG;
-                    g[5] = G * dLa;
-                    g[6] = dch * dpx0;
-                    g[7] = dch * dpx1;
-                    g[8] = dch * dpx2;
-                    T = hit ? Tn : T;
-                    acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
-                    lc0 = hit ? col.x : lc0; lc1 = hit ? col.y : lc1; lc2 = hit ? col.z : lc2;
-                    last_alpha = hit ? alpha : last_alpha;
+                    g[5] = Gh[k] * dLa[k];
+                    g[6] = dch[k] * dpx0;
+                    g[7] = dch[k] * dpx1;
+                    g[8] = dch[k] * dpx2;
 #pragma unroll
                     for (int c = 0; c < NACC; c++) g[c] = wave_sum_to_lane63(g[c]);
                     if (lane == 63) {
@@ -270,6 +285,11 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
             if (r[8] != 0.f) atomicAdd(a.dL_dcolor + 3 * (size_t)id + 2, r[8]);
         }
     }
+    __syncthreads();
+    if (tid == 0) {
+        a.tile_clock[4 * tile + 2] = clk0;
+        a.tile_clock[4 * tile + 3] = wall_clock64();
+    }
 }
 
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
@@ -278,7 +298,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView&
 {
     RenderBwdArgs a;
     a.ranges = iv.ranges;
-    a.tile_order = iv.tile_order;
+    a.tile_order = iv.tile_order_bwd;
     a.point_list = point_list;
     a.splat = g.splat;
     a.W = p.W; a.H = p.H;
@@ -292,7 +312,11 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView&
     a.dL_dconic = dL_dconic;
     a.dL_dopacity = dL_dopacity;
     a.dL_dcolor = dL_dcolor;
-    hipLaunchKernelGGL(k_render_backward, dim3(a.gridx * gridy), dim3(256), 0, L.stream, a);
+    a.tile_clock = iv.tile_clock;
+    // experiment knob: extra (unused) dynamic LDS caps how many tiles are resident per CU, which turns the
+    // hardware dispatcher into a longest-first dynamic scheduler
+    static const int lds_pad = getenv("GSR_RENDER_LDS_PAD") ? atoi(getenv("GSR_RENDER_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(k_render_backward, dim3(a.gridx * gridy), dim3(256), lds_pad, L.stream, a);
     return check_launch(L, "render_backward");
 }
 

@@ -3,26 +3,28 @@
 // Per-pixel arithmetic, thresholds and bookkeeping are those of reference CR/forward.cu:264-377
 // (renderCUDA): power > 0 skip, alpha = min(0.99, o*exp(power)), alpha < 1/255 skip, stop when
 // T*(1-alpha) < 1e-4 (that entry is not blended), C += colour*alpha*T, out = C + T*bg, plus final_T and
-// n_contrib for the backward pass.
+// n_contrib for the backward pass.  Tiles are the reference's 16x16 (they define keys and ranges).
 //
-// Mapping (ours): one 256-thread workgroup per 16x16 tile, four wave64s each owning an 8x8 pixel
-// quadrant.  The tile's Gaussian list is staged through LDS 256 entries at a time from the packed
-// 48-B Splat records (one gather per entry instead of three), as SoA so the inner loop's reads are
-// wave-uniform broadcasts.  The frame time of this kernel is set by the few longest tile lists (a wave
-// walks its list serially), so the inner loop is built for latency, not just throughput:
-//   - entries are taken GROUP at a time: all LDS reads of a group are issued together, the next group is
-//     prefetched into registers while the current one is evaluated, the G exp/alpha evaluations are
-//     independent (ILP), and only the short T / C recurrence is serial;
-//   - per-pixel skips are selects, not branches; the only branch is the wave-uniform "all 64 pixels
-//     done" ballot once per group, and the workgroup stops staging once all four waves are done;
-//   - tiles are dispatched in descending list-length order (tile_order) so the longest lists start first.
+// Mapping (ours): WAVE-AUTONOMOUS QUADRANTS.  The unit of work is one wave64 = one 8x8 quadrant of a tile
+// (four single-wave workgroups per tile).  A wave walks its tile's list on its own:
+//   - 64 list entries per round, one per lane: the lane gathers the entry's packed 48-B Splat record and
+//     decides with the exact-safe footprint test (tile_cull.hpp) whether the entry can matter to THIS quadrant;
+//     a ballot turns that into a 64-bit mask;
+//   - the mask is consumed four set bits at a time by scalar code (s_ff1 / s_and), the chosen lanes' records are
+//     broadcast with v_readlane into SGPRs, and the 64 pixels evaluate the four entries with scalar operands:
+//     no LDS, no barrier, no waiting for sibling quadrants (a quadrant of a silhouette tile that sees half the
+//     entries finishes in half the time and frees its SIMD slot);
+//   - the next round's records (and the ids of the round after) are already in flight while a round is
+//     evaluated, so the dependent id -> record gather latency is off the critical path;
+//   - per-pixel skips are selects; the only branches are wave-uniform (mask empty, all 64 pixels done).
+// The frame time of this kernel is set by the few longest lists (a wave walks its list serially); tiles are
+// dispatched in descending list-length order (tile_order) so those start first.
 #include "common.hpp"
 #include "tile_cull.hpp"
 
 namespace gsr {
 
-constexpr int RB = 256;  // entries staged per round
-constexpr int GRP = 4;   // entries evaluated per inner-loop trip
+constexpr int GRP = 4;  // entries evaluated per inner-loop trip
 
 struct RenderArgs {
     const uint2* ranges;
@@ -37,32 +39,56 @@ struct RenderArgs {
     uint32_t* tile_need;
 };
 
-struct EntryRegs {
-    float4 q0;   // x, y, conic.x, conic.y
-    float2 q1;   // conic.z, opacity
-    float4 col;  // r, g, b, -
-};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_render_forward(RenderArgs a)
+// Prefetch loads are issued as inline asm so that hipcc's waitcnt pass does not see them: left to itself it puts
+// an s_waitcnt for the NEXT round's records inside the CURRENT round's evaluation loop and re-exposes the gather
+// latency every 64 entries.  The loads are retired by hand with one s_waitcnt vmcnt(0) at the rotation point; that
+// asm takes the destination registers as in/out operands, so nothing can read them earlier.
+__device__ __forceinline__ void prefetch16(f32x4& dst, const void* p)
 {
-    __shared__ float4 s_q0[RB + 1];   // slot RB is the null entry (alpha = 0) used for padding
-    __shared__ float2 s_q1[RB + 1];
-    __shared__ float4 s_col[RB + 1];
-    __shared__ uint16_t s_list[4][RB + 2 * GRP];  // per quadrant: indices of the staged entries that may touch it
-    __shared__ uint32_t s_cnt[4][4];               // [quadrant][staging wave]
-    __shared__ uint32_t s_livew[2][4];
-    __shared__ uint32_t s_need;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void prefetch4(uint32_t& dst, const void* p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void retire_prefetch(f32x4& a, f32x4& b, f32x4& c, uint32_t& d)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
 
-    const uint32_t tile = a.tile_order[blockIdx.x];
+// exp(x) for the compositing loop.  Instruction-for-instruction the core of the ocml expf that `exp(power)` of the
+// reference resolves to under hipcc (extended-precision x*log2(e), v_rndne, v_exp_f32, v_ldexp_f32), minus its two
+// range clamps: x > 88.7 -> inf and x < -103.3 -> 0.  Neither can change a decision or a blended value: entries
+// with power > 0 are skipped before alpha is used, and for x < -103 both forms give a value < 1e-44, far below
+// the 1/255 cut for any finite opacity.  For every x in [-103, 0] the result is bit-identical to expf(x).
+__device__ __forceinline__ float exp_nonpos(float x)
+{
+    const float ph = x * 0x1.715476p+0f;
+    float pl = __builtin_fmaf(x, 0x1.715476p+0f, -ph);
+    pl = __builtin_fmaf(x, 0x1.4ae0bep-26f, pl);
+    const float e = __builtin_rintf(ph);
+    const float r = __builtin_amdgcn_exp2f((ph - e) + pl);
+    return __builtin_ldexpf(r, (int)e);
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+__global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
+{
+    const uint32_t tile = a.tile_order[blockIdx.x >> 2];
+    const uint32_t q = blockIdx.x & 3u;
+    const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // wave w owns quadrant (w&1, w>>1); lane -> (lane&7, lane>>3) inside it
-    const uint32_t px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
-    const uint32_t py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
+    const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixf_x = (float)px, pixf_y = (float)py;
-    const float tile_px = (float)(tx * TILE_X), tile_py = (float)(ty * TILE_Y);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const float x0f = (float)x0, y0f = (float)y0;
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -72,121 +98,124 @@ __global__ __launch_bounds__(256) void k_render_forward(RenderArgs a)
     uint32_t last_contributor = 0;
     uint32_t stop_at = 0;  // 1-based index of the entry that terminated this pixel
     bool done = !inside;
-    if (tid == 0) {
-        s_need = 0;
-        s_q0[RB] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: power = -0, alpha = 0 -> never passes 1/255
-        s_q1[RB] = make_float2(0.f, 0.f);
-        s_col[RB] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {
-        const bool wave_live = !__all(done);
-        if (lane == 0) s_livew[0][w] = wave_live ? 1u : 0u;
-    }
+    bool all_done = __all(done);
 
-    int round = 0;
-    for (int base = 0; base < total; base += RB, round++) {
-        // S0: everyone has finished reading the previous round's LDS and published its live flag.
-        __syncthreads();
-        // workgroup-wide early exit (reference: __syncthreads_count(done) == BLOCK_SIZE)
-        const uint32_t* lv = s_livew[round & 1];
-        if ((lv[0] | lv[1] | lv[2] | lv[3]) == 0u) break;
-
-        const int n = total - base < RB ? total - base : RB;
-        uint32_t qmask = 0;
-        if ((int)tid < n) {
-            const uint32_t id = a.point_list[range.x + base + tid];
-            const Splat* sp = a.splat + id;
-            const float4 q0 = sp->q0, q1 = sp->q1, q2 = sp->q2;
-            s_q0[tid] = q0;
-            s_q1[tid] = make_float2(q1.x, q1.y);
-            s_col[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
-            qmask = quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_px, tile_py);
-        }
-        uint64_t bal[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            bal[q] = __ballot((qmask >> q) & 1u);
-            if (lane == 0) s_cnt[q][w] = (uint32_t)__popcll(bal[q]);
-        }
-        __syncthreads();  // SA: counts visible
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t off = 0;
-#pragma unroll
-            for (int ww = 0; ww < 4; ww++)
-                if ((uint32_t)ww < w) off += s_cnt[q][ww];
-            if ((qmask >> q) & 1u) s_list[q][off + (uint32_t)__popcll(bal[q] & lt_mask)] = (uint16_t)tid;
-        }
-        // this wave's own quadrant list: length, padding with the null entry up to a whole group + one prefetch group
-        const int nq = (int)(s_cnt[w][0] + s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3]);
-        const int nq_pad = (nq + GRP - 1) / GRP * GRP;
-        if ((int)lane < nq_pad + GRP - nq) s_list[w][nq + lane] = (uint16_t)RB;
-        __syncthreads();  // SB: lists complete
-
-        if (!__all(done)) {
-            const uint16_t* lst = s_list[w];
-            EntryRegs cur[GRP], nxt[GRP];
-            uint32_t ci[GRP], ni[GRP];
-#pragma unroll
-            for (int k = 0; k < GRP; k++) {
-                ci[k] = lst[k];
-                cur[k].q0 = s_q0[ci[k]];
-                cur[k].q1 = s_q1[ci[k]];
-                cur[k].col = s_col[ci[k]];
-            }
-            for (int j0 = 0; j0 < nq_pad; j0 += GRP) {
-                // prefetch the next group (the list is padded by one extra group of null entries)
-#pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    ni[k] = lst[j0 + GRP + k];
-                    nxt[k].q0 = s_q0[ni[k]];
-                    nxt[k].q1 = s_q1[ni[k]];
-                    nxt[k].col = s_col[ni[k]];
-                }
-                float alpha[GRP];
-                bool vis[GRP];
-#pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    const float dx = cur[k].q0.x - pixf_x, dy = cur[k].q0.y - pixf_y;
-                    const float power = -0.5f * (cur[k].q0.z * dx * dx + cur[k].q1.x * dy * dy) - cur[k].q0.w * dx * dy;
-                    alpha[k] = fminf(0.99f, cur[k].q1.y * expf(power));
-                    vis[k] = !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
-                }
-#pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    const float test_T = T * (1 - alpha[k]);
-                    const bool hit = !done && vis[k];
-                    const bool stop = hit && (test_T < 0.0001f);
-                    const bool blend = hit && !stop;
-                    // adding +0 leaves C unchanged bit-for-bit (C is never -0)
-                    C0 += blend ? cur[k].col.x * alpha[k] * T : 0.f;
-                    C1 += blend ? cur[k].col.y * alpha[k] * T : 0.f;
-                    C2 += blend ? cur[k].col.z * alpha[k] * T : 0.f;
-                    T = blend ? test_T : T;
-                    const uint32_t idx1 = (uint32_t)base + ci[k] + 1u;  // 1-based position in the tile list
-                    last_contributor = blend ? idx1 : last_contributor;
-                    stop_at = stop ? idx1 : stop_at;
-                    done = done || stop;
-                }
-                if (__all(done)) break;
-#pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    cur[k] = nxt[k];
-                    ci[k] = ni[k];
-                }
-            }
-        }
+    if (!all_done && total > 0) {
+        const uint32_t* plist = a.point_list + range.x;
+        // software pipeline: records of round r+1 and ids of round r+2 are in flight while round r is evaluated.
+        // Lanes past the end of the list read entry total-1 again (always a valid address) and are masked by `valid`.
+        const int last = total - 1;
+        f32x4 c0, c1, c2, n0, n1, n2;
+        uint32_t id_nxt, id_nn;
         {
-            const bool wave_live = !__all(done);
-            if (lane == 0) s_livew[(round + 1) & 1][w] = wave_live ? 1u : 0u;
+            // prologue: round 0's records and round 1's ids, through the same asm path so that no compiler-tracked
+            // load is pending when the loop is entered
+            uint32_t id0;
+            prefetch4(id0, plist + ((int)lane < total ? (int)lane : last));
+            prefetch4(id_nxt, plist + (64 + (int)lane < total ? 64 + (int)lane : last));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(id0), "+v"(id_nxt)::"memory");
+            const Splat* sp = a.splat + id0;
+            prefetch16(c0, &sp->q0);
+            prefetch16(c1, &sp->q1);
+            prefetch16(c2, &sp->q2);
+            retire_prefetch(c0, c1, c2, id_nxt);
+        }
+        for (int base = 0; base < total; base += 64) {
+            {
+                const Splat* sp = a.splat + id_nxt;
+                prefetch16(n0, &sp->q0);
+                prefetch16(n1, &sp->q1);
+                prefetch16(n2, &sp->q2);
+                const int i2 = base + 128 + (int)lane;
+                prefetch4(id_nn, plist + (i2 < total ? i2 : last));
+            }
+
+            // which of this round's 64 entries can reach alpha >= 1/255 somewhere in this quadrant?
+            const bool valid = base + (int)lane < total;
+            const bool touch = valid && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
+            uint64_t mask = __ballot(touch);
+
+            while (mask != 0 && !all_done) {
+                float ex[GRP], ey[GRP], eA[GRP], eB[GRP], eC[GRP], eo[GRP], er[GRP], eg[GRP], eb[GRP];
+                uint32_t eidx[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; k++) {
+                    const bool have = mask != 0;
+                    const int j = have ? (int)__builtin_ctzll(mask) : 0;
+                    mask = have ? (mask & (mask - 1)) : 0;
+                    ex[k] = lane_bcast(c0.x, j); ey[k] = lane_bcast(c0.y, j);
+                    eA[k] = lane_bcast(c0.z, j); eB[k] = lane_bcast(c0.w, j);
+                    eC[k] = lane_bcast(c1.x, j);
+                    const float o = lane_bcast(c1.y, j);
+                    eo[k] = have ? o : 0.f;  // opacity 0 -> alpha 0 -> the 1/255 test drops the slot
+                    er[k] = lane_bcast(c1.z, j); eg[k] = lane_bcast(c1.w, j); eb[k] = lane_bcast(c2.x, j);
+                    eidx[k] = (uint32_t)(base + j + 1);  // 1-based position in the tile list
+                }
+                // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0
+                float alpha[GRP], ae[GRP];
+                bool cnt[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; k++) {
+                    const float dx = ex[k] - pixf_x, dy = ey[k] - pixf_y;
+                    const float power = -0.5f * (eA[k] * dx * dx + eC[k] * dy * dy) - eB[k] * dx * dy;
+                    alpha[k] = fminf(0.99f, eo[k] * exp_nonpos(power));
+                    cnt[k] = !done && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+                    ae[k] = cnt[k] ? alpha[k] : 0.f;
+                }
+                // Optimistic pass: assume no pixel of this wave terminates inside the group.  T then only needs the
+                // products T*(1-ae) (ae = 0 multiplies by exactly 1), and because T never increases and every live
+                // pixel has T >= 1e-4, "some entry of the group would have stopped a pixel" is just T_after < 1e-4.
+                // A pixel stops once, so the exact serial fallback runs for at most 64 groups per wave per tile.
+                float Tk[GRP + 1];
+                Tk[0] = T;
+#pragma unroll
+                for (int k = 0; k < GRP; k++) Tk[k + 1] = Tk[k] * (1 - ae[k]);
+                if (!__any(Tk[GRP] < 0.0001f)) {
+#pragma unroll
+                    for (int k = 0; k < GRP; k++) {
+                        // ae = 0 adds a zero, which leaves C unchanged bit-for-bit (C is never -0)
+                        C0 += er[k] * ae[k] * Tk[k];
+                        C1 += eg[k] * ae[k] * Tk[k];
+                        C2 += eb[k] * ae[k] * Tk[k];
+                        last_contributor = cnt[k] ? eidx[k] : last_contributor;
+                    }
+                    T = Tk[GRP];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < GRP; k++) {
+                        const float test_T = T * (1 - alpha[k]);
+                        const bool hit = !done && cnt[k];
+                        const bool stop = hit && (test_T < 0.0001f);
+                        const bool blend = hit && !stop;
+                        C0 += blend ? er[k] * alpha[k] * T : 0.f;
+                        C1 += blend ? eg[k] * alpha[k] * T : 0.f;
+                        C2 += blend ? eb[k] * alpha[k] * T : 0.f;
+                        T = blend ? test_T : T;
+                        last_contributor = blend ? eidx[k] : last_contributor;
+                        stop_at = stop ? eidx[k] : stop_at;
+                        done = done || stop;
+                    }
+                    all_done = __all(done);
+                }
+            }
+            retire_prefetch(n0, n1, n2, id_nn);
+            if (all_done) break;
+            c0 = n0; c1 = n1; c2 = n2;
+            id_nxt = id_nn;
         }
     }
 
-    // instrumentation: how many list entries this tile really needed (max over its pixels)
-    __syncthreads();
-    if (inside) atomicMax(&s_need, done ? stop_at : (uint32_t)total);
-    __syncthreads();
-    if (tid == 0) a.tile_need[tile] = s_need;
+    // instrumentation: how many list entries this tile really needed (max over its pixels); tile_need is zeroed
+    // before the launch
+    {
+        uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(need, d, 64);
+            need = need > o ? need : o;
+        }
+        if (lane == 0 && need != 0) atomicMax(&a.tile_need[tile], need);
+    }
 
     if (inside) {
         const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
@@ -214,7 +243,9 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& 
     a.final_T = iv.final_T;
     a.n_contrib = iv.n_contrib;
     a.tile_need = iv.tile_need;
-    hipLaunchKernelGGL(k_render_forward, dim3(a.gridx * gridy), dim3(256), 0, L.stream, a);
+    const int T = a.gridx * gridy;
+    if (hipMemsetAsync(iv.tile_need, 0, (size_t)T * sizeof(uint32_t), L.stream) != hipSuccess) return GSR_ERR_HIP;
+    hipLaunchKernelGGL(k_render_forward, dim3(4 * T), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_forward");
 }
 

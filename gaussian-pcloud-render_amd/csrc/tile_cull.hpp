@@ -3,7 +3,7 @@
 // A 16x16 tile's list (built from each Gaussian's 3-sigma bounding SQUARE in tile units, reference
 // CR/auxiliary.h:46-56) holds many entries that cannot reach alpha >= 1/255 at any pixel of a given 8x8
 // quadrant.  The reference evaluates them anyway and skips them pixel by pixel (CR/forward.cu:336-347); here
-// the staging thread decides once per (entry, quadrant) and a wave only walks the entries that may matter.
+// the staging lane decides once per (entry, quadrant) and a wave only walks the entries that may matter.
 // Skipping is invisible in the results as long as it is CONSERVATIVE: an entry is dropped for a quadrant only
 // when  max over the quadrant's pixel centres of power(d) + E  <  log(1/(255*opacity)),  where
 // power(d) = -0.5 (A dx^2 + C dy^2) - B dx dy is concave for a positive-definite conic, its maximum over a
@@ -16,40 +16,44 @@ namespace gsr {
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// 4-bit mask: bit q set if the Gaussian may contribute to quadrant q = (qx | qy<<1) of the tile whose
-// first pixel is (tile_px, tile_py).  mean (mx,my), conic (A,B,C), opacity o.
+// May the Gaussian (mean (mx,my), conic (A,B,C), opacity o) reach alpha >= 1/255 at a pixel centre of the 8x8
+// block whose first pixel is (x0,y0)?  false = provably not.
+__device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float B, float C, float o, float x0, float y0)
+{
+    if (!(o == o) || !(A == A) || !(B == B) || !(C == C) || !(mx == mx) || !(my == my)) return true;  // NaN: keep
+    if (!(o > 0.f)) return false;  // alpha = o*exp(..) <= 0 < 1/255 at every pixel
+    if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;  // not provably concave: keep
+    const float thr = -__logf(255.0f * o);  // alpha >= 1/255  <=>  power >= thr
+    // d = mean - pixel, pixel centres span [x0, x0+7] x [y0, y0+7]
+    const float dxl = mx - (x0 + 7.f), dxh = mx - x0, dyl = my - (y0 + 7.f), dyh = my - y0;
+    float m;
+    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) {
+        m = 0.f;  // the mean lies inside the block
+    } else {
+        m = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float ex = e ? dxh : dxl;
+            const float yy = clampf(-B * ex / C, dyl, dyh);
+            m = fmaxf(m, -0.5f * (A * ex * ex + C * yy * yy) - B * ex * yy);
+            const float ey = e ? dyh : dyl;
+            const float xx = clampf(-B * ey / A, dxl, dxh);
+            m = fmaxf(m, -0.5f * (A * xx * xx + C * ey * ey) - B * xx * ey);
+        }
+    }
+    const float ax = fmaxf(fabsf(dxl), fabsf(dxh)), ay = fmaxf(fabsf(dyl), fabsf(dyh));
+    const float E = 1.0e-5f * (A * ax * ax + C * ay * ay + fabsf(B) * ax * ay) + 1.0e-4f + 1.0e-5f * fabsf(thr);
+    return !(m + E < thr);
+}
+
+// 4-bit mask over the quadrants q = (qx | qy<<1) of the 16x16 tile whose first pixel is (tile_px, tile_py).
 __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float o, float tile_px,
                                                   float tile_py)
 {
-    if (!(o == o) || !(A == A) || !(B == B) || !(C == C) || !(mx == mx) || !(my == my)) return 0xFu;  // NaN: keep
-    if (!(o > 0.f)) return 0u;  // alpha = o*exp(..) <= 0 < 1/255 at every pixel
-    if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return 0xFu;  // not provably concave: keep
-    const float thr = -__logf(255.0f * o);  // alpha >= 1/255  <=>  power >= thr
     uint32_t mask = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float x0 = tile_px + (float)((q & 1) * 8), y0 = tile_py + (float)((q >> 1) * 8);
-        // d = mean - pixel, pixel centres span [x0, x0+7] x [y0, y0+7]
-        const float dxl = mx - (x0 + 7.f), dxh = mx - x0, dyl = my - (y0 + 7.f), dyh = my - y0;
-        float m;
-        if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) {
-            m = 0.f;  // the mean lies inside the quadrant
-        } else {
-            m = -3.0e38f;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float ex = e ? dxh : dxl;
-                const float yy = clampf(-B * ex / C, dyl, dyh);
-                m = fmaxf(m, -0.5f * (A * ex * ex + C * yy * yy) - B * ex * yy);
-                const float ey = e ? dyh : dyl;
-                const float xx = clampf(-B * ey / A, dxl, dxh);
-                m = fmaxf(m, -0.5f * (A * xx * xx + C * ey * ey) - B * xx * ey);
-            }
-        }
-        const float ax = fmaxf(fabsf(dxl), fabsf(dxh)), ay = fmaxf(fabsf(dyl), fabsf(dyh));
-        const float E = 1.0e-5f * (A * ax * ax + C * ay * ay + fabsf(B) * ax * ay) + 1.0e-4f + 1.0e-5f * fabsf(thr);
-        if (!(m + E < thr)) mask |= 1u << q;
-    }
+    for (int q = 0; q < 4; q++)
+        if (may_touch_8x8(mx, my, A, B, C, o, tile_px + (float)((q & 1) * 8), tile_py + (float)((q >> 1) * 8))) mask |= 1u << q;
     return mask;
 }
 
