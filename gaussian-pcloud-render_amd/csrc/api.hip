@@ -13,6 +13,7 @@
 //             tile order by list length       (3 tiny launches)
 //             render                          (1 launch)
 //   backward  render backward, per-Gaussian backward (2 launches)
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -317,6 +318,51 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
                            b.val[res], dst);
         if (hipGetLastError() != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query kernel failed");
     }
+    return GSR_OK;
+}
+
+// Device self-test of internal primitives that have no observable output of their own: the transposed wave
+// reduction of the backward pass, and the stable radix sort against std::stable_sort on random keys with many ties.
+int gsr_selftest(gsr_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    float* d = nullptr;
+    if (hipMalloc(&d, 128 * sizeof(float)) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
+    const int rr = selftest_reduce(s, d);
+    (void)hipFree(d);
+    if (rr != 0) return fail(GSR_ERR_HIP, "[gsr] selftest: wave reduction wrong at check %d", rr);
+
+    const int64_t n = 100003;
+    std::vector<uint32_t> hk(n), hv(n), order(n);
+    uint32_t x = 12345u;
+    for (int64_t i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        hk[i] = (x >> 8) % 3001u;  // many ties
+        hv[i] = (uint32_t)i;
+        order[i] = (uint32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
+    uint32_t *k0, *k1, *v0, *v1, *hist, *tot;
+    const size_t nb = (size_t)div_up(n, RS_TILE);
+    if (hipMalloc(&k0, n * 4) != hipSuccess || hipMalloc(&k1, n * 4) != hipSuccess || hipMalloc(&v0, n * 4) != hipSuccess ||
+        hipMalloc(&v1, n * 4) != hipSuccess || hipMalloc(&hist, RADIX * nb * 4) != hipSuccess || hipMalloc(&tot, RADIX * 4) != hipSuccess)
+        return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
+    (void)hipMemcpyAsync(k0, hk.data(), n * 4, hipMemcpyHostToDevice, s);
+    uint32_t* key[2] = {k0, k1};
+    uint32_t* val[2] = {v0, v1};
+    int res = 0;
+    const Launch L{s, 1};
+    int rc = launch_radix_sort_pairs(L, n, key, val, /*iota_vals=*/true, 12, hist, tot, &res);
+    std::vector<uint32_t> gk(n), gv(n);
+    if (rc == 0) {
+        (void)hipMemcpyAsync(gk.data(), key[res], n * 4, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(gv.data(), val[res], n * 4, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = GSR_ERR_HIP;
+    }
+    (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(hist); (void)hipFree(tot);
+    if (rc != 0) return rc;
+    for (int64_t i = 0; i < n; i++)
+        if (gv[i] != order[i] || gk[i] != hk[order[i]]) return fail(GSR_ERR_HIP, "[gsr] selftest: radix sort differs from std::stable_sort at %lld", (long long)i);
     return GSR_OK;
 }
 

@@ -178,6 +178,7 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& 
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
                            const ImageView& iv, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                            float* dL_dopacity, float* dL_dcolor);
+int selftest_reduce(hipStream_t stream, float* d_scratch128);
 // preprocess_bwd.hip
 int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,
                                const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolor,

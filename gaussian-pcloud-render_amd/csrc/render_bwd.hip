@@ -2,51 +2,156 @@
 // opacity, colour}.
 //
 // Per-(pixel, Gaussian) arithmetic follows reference CR/backward.cu:399-557 (renderCUDA): the tile list is
-// walked back to front, entries at or beyond the pixel's n_contrib are skipped, T is rebuilt by division,
-// the same power/alpha skips apply, and nine partial derivatives come out of every contributing pair.
+// walked back to front, entries at or beyond the pixel's n_contrib are skipped, T is rebuilt by dividing out
+// (1 - alpha), the same power/alpha skips apply, and nine partial derivatives come out of every contributing pair.
 //
-// Where the reference issues 9 float atomicAdds per contributing PAIR (256 pixels hammering the same
-// Gaussian), this kernel reduces first:
-//   lanes -> wave   : 6-step DPP butterfly per value (quad_perm, row mirrors, row_bcast15/31)
-//   waves -> tile   : LDS float adds into a per-round accumulator row per list entry
-//   tile  -> global : one hardware float atomic per (entry, component) per tile, zero sums skipped
-// so global atomics drop from 9*256 to at most 9 per (tile, entry).  The walk also starts at the tile's
-// largest n_contrib instead of the list end: entries no pixel of the tile consumed are never staged.
-// Summation order differs from the reference's (undefined) atomic order; results agree to fp32 rounding.
-#include <cstdlib>
-
+// Mapping (ours), same wave-autonomous scheme as render_fwd.hip: one wave64 = one 8x8 quadrant walks the list on
+// its own (64 entries per round gathered one per lane, exact-safe footprint test + ballot, four surviving entries
+// at a time broadcast with v_readlane), starting at the largest n_contrib of ITS 64 pixels: entries nobody in
+// the quadrant consumed are never touched.  No LDS, no barrier.
+//
+// Where the reference issues 9 float atomicAdds per contributing PAIR (up to 256 pixels hammering one Gaussian),
+// the 4 x 9 partial sums of a group are reduced over the 64 lanes FIRST, by a transposed butterfly: at every
+// level a lane keeps half of its values and hands the other half to its partner, so 32 values cost 72 instructions
+// instead of 32 x 6 (v_permlane32_swap / v_permlane16_swap for lane bits 5 and 4, DPP row_ror:8, row_shl/shr:4 and
+// quad_perm for bits 3..0).  Afterwards lane 2i holds the wave total of value i, and ONE global float atomic
+// instruction per group (36 active lanes, zero sums skipped) updates the per-Gaussian gradients: at most 9 atomics
+// per (quadrant, entry) instead of 9 x 64.
+// Summation order differs from the reference's (undefined) atomic order and 1/(1-alpha) is v_rcp_f32 (1 ulp);
+// results agree to fp32 rounding (tests: <= 2e-4 of max|g| per tensor, observed ~1e-6).
 #include "common.hpp"
 #include "tile_cull.hpp"
 
 namespace gsr {
 
-constexpr int BRB = 256;   // entries staged per round
-constexpr int BGRP = 4;    // entries evaluated per inner-loop trip (see render_fwd.hip for the latency rationale)
-constexpr int NACC = 9;    // mean2D.x,y  conic.x,y,w  opacity  colour r,g,b
+constexpr int BGRP = 4;  // entries evaluated per inner-loop trip
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_get(float v)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// see render_fwd.hip: prefetch loads hidden from hipcc's waitcnt pass, retired by hand
+__device__ __forceinline__ void bw_prefetch16(f32x4& dst, const void* p)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void bw_prefetch4(uint32_t& dst, const void* p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 
-// sum over the 64 lanes; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+__device__ __forceinline__ float bw_bcast(float v, int src_lane)
 {
-    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
-    v += dpp_get<0x140, 0xf>(v);  // row_mirror
-    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-    return v;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
-struct BEntry {
-    float4 q0;   // x, y, conic.x, conic.y
-    float2 q1;   // conic.z, opacity
-    float4 col;  // r, g, b, -
-};
+// core of ocml expf without its range clamps; bit-identical to expf on [-103, 0] (see render_fwd.hip)
+__device__ __forceinline__ float bw_exp_nonpos(float x)
+{
+    const float ph = x * 0x1.715476p+0f;
+    float pl = __builtin_fmaf(x, 0x1.715476p+0f, -ph);
+    pl = __builtin_fmaf(x, 0x1.4ae0bep-26f, pl);
+    const float e = __builtin_rintf(ph);
+    const float r = __builtin_amdgcn_exp2f((ph - e) + pl);
+    return __builtin_ldexpf(r, (int)e);
+}
+
+// ---- cross-lane helpers -------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float xor1(float v) { return dpp_mov<0xB1, 0xf, 0xf>(0.f, v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float xor2(float v) { return dpp_mov<0x4E, 0xf, 0xf>(0.f, v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float xor8(float v) { return dpp_mov<0x128, 0xf, 0xf>(0.f, v); }  // row_ror:8
+__device__ __forceinline__ float xor4(float v)
+{
+    // banks 1,3 take lane-4 (row_shr:4), banks 0,2 take lane+4 (row_shl:4)
+    const float t = dpp_mov<0x114, 0xf, 0xa>(0.f, v);
+    return dpp_mov<0x104, 0xf, 0x5>(t, v);
+}
+// v_permlane32_swap a, b : lanes 32-63 of a <-> lanes 0-31 of b, i.e. a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32];
+// v_permlane16_swap a, b : odd rows of a <-> even rows of b,  a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3].
+// a' + b' then holds, in the lanes whose bit 5 (resp. 4) is 0, a summed over the lane pair, and in the other lanes b
+// summed over the pair: one halving level of the transposed reduction for two instructions per value pair.
+// Issued as inline asm, eight swaps per statement: (1) clang 22 / ROCm 7.2 lowers __builtin_amdgcn_permlane{16,32}_swap
+// so that both elements of its result are the FIRST output (the IR adds extractvalue 0 to itself), (2) hipcc pads no
+// wait states inside asm, so each block carries its own s_nop 1 in front (VALU write -> permlane swap read, 2 wait
+// states on gfx950) and behind (swap write -> VALU read).
+#define GSR_SWAP8(OP, A, B)                                                                                               \
+    asm volatile("s_nop 1\n\t" OP " %0, %8\n\t" OP " %1, %9\n\t" OP " %2, %10\n\t" OP " %3, %11\n\t" OP " %4, %12\n\t" OP \
+                 " %5, %13\n\t" OP " %6, %14\n\t" OP " %7, %15\n\ts_nop 1"                                                \
+                 : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(B[0]),   \
+                   "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]))
+#define GSR_SWAP2(OP, A0, A1, B0, B1)                                                                  \
+    asm volatile("s_nop 1\n\t" OP " %0, %2\n\t" OP " %1, %3\n\ts_nop 1" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1))
+
+// Transposed reduction of 32 per-lane values over the 64 lanes: on return lane l holds the wave-wide sum of
+// v[(l >> 1) & 31].  ~75 instructions instead of 32 x 6.
+__device__ __forceinline__ float reduce32_transposed(const float (&v)[32], uint32_t lane)
+{
+    float a[8], b[8], r[16], s[8], t[4], u[2];
+    // bit 5: pairs (v[i], v[i+16]) -> r[i] = value i + 16*b5
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = v[8 * h + i]; b[i] = v[8 * h + i + 16]; }
+        GSR_SWAP8("v_permlane32_swap_b32", a, b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[8 * h + i] = a[i] + b[i];
+    }
+    // bit 4: pairs (r[i], r[i+8]) -> s[i] = value i + 8*b4 + 16*b5
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = r[i]; b[i] = r[i + 8]; }
+    GSR_SWAP8("v_permlane16_swap_b32", a, b);
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = a[i] + b[i];
+    const bool b3 = (lane & 8u) != 0, b2 = (lane & 4u) != 0, b1 = (lane & 2u) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = (b3 ? s[i + 4] : s[i]) + xor8(b3 ? s[i] : s[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) u[i] = (b2 ? t[i + 2] : t[i]) + xor4(b2 ? t[i] : t[i + 2]);
+    float w = (b1 ? u[1] : u[0]) + xor2(b1 ? u[0] : u[1]);
+    w += xor1(w);
+    return w;
+}
+// 4 values: on return every lane of row r holds the wave-wide sum of x[r].
+__device__ __forceinline__ float reduce4_rows(float x0, float x1, float x2, float x3)
+{
+    GSR_SWAP2("v_permlane32_swap_b32", x0, x1, x2, x3);
+    float y0 = x0 + x2, y1 = x1 + x3;  // value (0|1) + 2*b5
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(y0), "+v"(y1));
+    float z = y0 + y1;                  // value b4 + 2*b5
+    z += xor1(z);
+    z += xor2(z);
+    z += dpp_mov<0x141, 0xf, 0xf>(0.f, z);  // row_half_mirror
+    z += dpp_mov<0x140, 0xf, 0xf>(0.f, z);  // row_mirror
+    return z;
+}
+
+// ---- self-test of the cross-lane reduction (gsr_selftest) ------------------------------------------------
+__global__ void k_selftest_reduce(float* out32, float* out4)
+{
+    const uint32_t lane = threadIdx.x;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = (float)((lane + 1) * (i + 1));  // wave sum = (i+1) * 2080
+    out32[lane] = reduce32_transposed(v, lane);
+    out4[lane] = reduce4_rows((float)(lane + 1), (float)(2 * (lane + 1)), (float)(3 * (lane + 1)), (float)(4 * (lane + 1)));
+}
+
+int selftest_reduce(hipStream_t stream, float* d_scratch128)
+{
+    hipLaunchKernelGGL(k_selftest_reduce, dim3(1), dim3(64), 0, stream, d_scratch128, d_scratch128 + 64);
+    float h[128];
+    if (hipMemcpyAsync(h, d_scratch128, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    for (int l = 0; l < 64; l++) {
+        if (h[l] != (float)(((l >> 1) + 1) * 2080)) return 1 + l;
+        if (h[64 + l] != (float)(((l >> 4) + 1) * 2080)) return 101 + l;
+    }
+    return 0;
+}
 
 struct RenderBwdArgs {
     const uint2* ranges;
@@ -62,50 +167,24 @@ struct RenderBwdArgs {
     float* dL_dconic;    // [P,4]
     float* dL_dopacity;  // [P]
     float* dL_dcolor;    // [P,3]
-    uint64_t* tile_clock;
 };
 
-__global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
+__global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
-    __shared__ float4 s_q0[BRB + 1];   // x, y, conic.x, conic.y   (slot BRB = null entry used for padding)
-    __shared__ float2 s_q1[BRB + 1];   // conic.z, opacity
-    __shared__ float4 s_col[BRB + 1];  // r, g, b, -
-    __shared__ uint32_t s_id[BRB];
-    __shared__ float s_acc[BRB + 1][NACC];
-    __shared__ uint16_t s_list[4][BRB + 2 * BGRP];  // per quadrant: staged entries that may touch it (tile_cull.hpp)
-    __shared__ uint32_t s_cnt[4][4];
-    __shared__ uint32_t s_max[4];
-
-    const uint32_t tile = a.tile_order[blockIdx.x];
-    const uint64_t clk0 = wall_clock64();
+    const uint32_t tile = a.tile_order[blockIdx.x >> 2];
+    const uint32_t q = blockIdx.x & 3u;
+    const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t px = tx * TILE_X + (w & 1) * 8 + (lane & 7);
-    const uint32_t py = ty * TILE_Y + (w >> 1) * 8 + (lane >> 3);
+    const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
+    const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixf_x = (float)px, pixf_y = (float)py;
-    const float tile_px = (float)(tx * TILE_X), tile_py = (float)(ty * TILE_Y);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const float x0f = (float)x0, y0f = (float)y0;
     const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
 
-    const uint2 range = a.ranges[tile];
-
-    const float T_final = inside ? a.final_T[pix] : 0.f;
-    float T = T_final;
     const uint32_t last_contributor = inside ? a.n_contrib[pix] : 0u;
-    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
-    if (inside) {
-        dpx0 = a.dL_dpix[pix];
-        dpx1 = a.dL_dpix[N + pix];
-        dpx2 = a.dL_dpix[2 * N + pix];
-    }
-    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-    float bg_dot_dpixel = 0;
-    bg_dot_dpixel += bg0 * dpx0;
-    bg_dot_dpixel += bg1 * dpx1;
-    bg_dot_dpixel += bg2 * dpx2;
-
-    // tile-wide max of n_contrib: nothing beyond it was consumed by any pixel
+    // entries [0, total) are walked, last first: nothing beyond the quadrant's largest n_contrib was consumed here
+    int total;
     {
         uint32_t m = last_contributor;
 #pragma unroll
@@ -113,182 +192,171 @@ __global__ __launch_bounds__(256) void k_render_backward(RenderBwdArgs a)
             const uint32_t o = __shfl_xor(m, d, 64);
             m = m > o ? m : o;
         }
-        if (lane == 0) s_max[w] = m;
+        total = (int)m;
     }
-    __syncthreads();
-    uint32_t max_nc = s_max[0];
-    max_nc = max_nc > s_max[1] ? max_nc : s_max[1];
-    max_nc = max_nc > s_max[2] ? max_nc : s_max[2];
-    max_nc = max_nc > s_max[3] ? max_nc : s_max[3];
-    const int total = (int)max_nc;  // list entries [0,total) are walked, last first
+    if (total == 0) return;
 
-    float acc_r0 = 0.f, acc_r1 = 0.f, acc_r2 = 0.f;      // accum_rec
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last_color
+    const uint2 range = a.ranges[tile];
+    const float T_final = inside ? a.final_T[pix] : 0.f;
+    float T = T_final;
+    float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+    if (inside) {
+        dpx0 = a.dL_dpix[pix];
+        dpx1 = a.dL_dpix[N + pix];
+        dpx2 = a.dL_dpix[2 * N + pix];
+    }
+    float bg_dot_dpixel = 0;
+    bg_dot_dpixel += a.bg[0] * dpx0;
+    bg_dot_dpixel += a.bg[1] * dpx1;
+    bg_dot_dpixel += a.bg[2] * dpx2;
     const float ddelx_dx = (float)(0.5 * a.W);
     const float ddely_dy = (float)(0.5 * a.H);
 
-    if (tid == 0) {
-        s_q0[BRB] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: alpha = 0, never hits
-        s_q1[BRB] = make_float2(0.f, 0.f);
-        s_col[BRB] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3,
+    // component c = i & 7 in {mean2D.x, mean2D.y, conic.x, conic.y, conic.w, colour r, g, b}; odd lanes 1, 17, 33, 49
+    // own the opacity gradient of entries 0..3.  target = base + id * stride.
+    char* tgt_base = nullptr;
+    uint32_t tgt_stride = 0;
+    int tgt_k = 0;
+    bool tgt_on = false;
+    if ((lane & 1u) == 0) {
+        const uint32_t i = lane >> 1, c = i & 7u;
+        tgt_k = (int)(i >> 3);
+        tgt_on = true;
+        if (c < 2) { tgt_base = (char*)(a.dL_dmean2D + c); tgt_stride = 12; }
+        else if (c < 5) { tgt_base = (char*)(a.dL_dconic + (c == 4 ? 3 : c - 2)); tgt_stride = 16; }
+        else { tgt_base = (char*)(a.dL_dcolor + (c - 5)); tgt_stride = 12; }
+    } else if ((lane & 15u) == 1) {
+        tgt_k = (int)(lane >> 4);
+        tgt_on = true;
+        tgt_base = (char*)a.dL_dopacity;
+        tgt_stride = 4;
     }
 
-    for (int base = 0; base < total; base += BRB) {
-        const int n = total - base < BRB ? total - base : BRB;
-        __syncthreads();  // previous round's flush is finished before LDS is reused
-        uint32_t qmask = 0;
-        if ((int)tid < n) {
-            const uint32_t id = a.point_list[range.x + (uint32_t)(total - 1 - base - (int)tid)];
-            const Splat* sp = a.splat + id;
-            const float4 q0 = sp->q0, q1 = sp->q1, q2 = sp->q2;
-            s_id[tid] = id;
-            s_q0[tid] = q0;
-            s_q1[tid] = make_float2(q1.x, q1.y);
-            s_col[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);
-            qmask = quadrant_mask(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tile_px, tile_py);
-        }
-        for (int i = tid; i < (BRB + 1) * NACC; i += 256) (&s_acc[0][0])[i] = 0.f;
-        uint64_t bal[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            bal[q] = __ballot((qmask >> q) & 1u);
-            if (lane == 0) s_cnt[q][w] = (uint32_t)__popcll(bal[q]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t off = 0;
-#pragma unroll
-            for (int ww = 0; ww < 4; ww++)
-                if ((uint32_t)ww < w) off += s_cnt[q][ww];
-            if ((qmask >> q) & 1u) s_list[q][off + (uint32_t)__popcll(bal[q] & lt_mask)] = (uint16_t)tid;
-        }
-        const int nq = (int)(s_cnt[w][0] + s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3]);
-        const int nq_pad = (nq + BGRP - 1) / BGRP * BGRP;
-        if ((int)lane < nq_pad + BGRP - nq) s_list[w][nq + lane] = (uint16_t)BRB;
-        __syncthreads();
+    float acc_r0 = 0.f, acc_r1 = 0.f, acc_r2 = 0.f;           // accum_rec
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last_color
 
-        const uint16_t* lst = s_list[w];
-        BEntry cur[BGRP], nxt[BGRP];
-        uint32_t ci[BGRP], ni[BGRP];
-#pragma unroll
-        for (int k = 0; k < BGRP; k++) {
-            ci[k] = lst[k];
-            cur[k].q0 = s_q0[ci[k]];
-            cur[k].q1 = s_q1[ci[k]];
-            cur[k].col = s_col[ci[k]];
+    const uint32_t* plist = a.point_list + range.x;
+    // Round r covers front indices hi-64 .. hi-1 (hi = total - 64 r), lane i <-> f = hi-1-i, so the lowest set bit of
+    // the ballot is the entry nearest the back.  Lanes whose f would be negative re-read entry 0 and are masked.
+    f32x4 c0, c1, c2, n0, n1, n2;
+    uint32_t id_cur, id_nxt, id_nn;
+    {
+        const int f0 = total - 1 - (int)lane, f1 = total - 65 - (int)lane;
+        bw_prefetch4(id_cur, plist + (f0 >= 0 ? f0 : 0));
+        bw_prefetch4(id_nxt, plist + (f1 >= 0 ? f1 : 0));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
+        const Splat* sp = a.splat + id_cur;
+        bw_prefetch16(c0, &sp->q0);
+        bw_prefetch16(c1, &sp->q1);
+        bw_prefetch16(c2, &sp->q2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2)::"memory");
+    }
+    for (int hi = total; hi > 0; hi -= 64) {
+        {
+            const Splat* sp = a.splat + id_nxt;
+            bw_prefetch16(n0, &sp->q0);
+            bw_prefetch16(n1, &sp->q1);
+            bw_prefetch16(n2, &sp->q2);
+            const int f2 = hi - 129 - (int)lane;
+            bw_prefetch4(id_nn, plist + (f2 >= 0 ? f2 : 0));
         }
-        for (int j0 = 0; j0 < nq_pad; j0 += BGRP) {
+        const int f_lane = hi - 1 - (int)lane;
+        const bool touch = f_lane >= 0 && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
+        uint64_t mask = __ballot(touch);
+
+        while (mask != 0) {
+            float ex[BGRP], ey[BGRP], eA[BGRP], eB[BGRP], eC[BGRP], eo[BGRP], er[BGRP], eg[BGRP], eb[BGRP];
+            uint32_t ef[BGRP], eid[BGRP];
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
-                ni[k] = lst[j0 + BGRP + k];
-                nxt[k].q0 = s_q0[ni[k]];
-                nxt[k].q1 = s_q1[ni[k]];
-                nxt[k].col = s_col[ni[k]];
+                const bool have = mask != 0;
+                const int j = have ? (int)__builtin_ctzll(mask) : 0;
+                mask = have ? (mask & (mask - 1)) : 0;
+                ex[k] = bw_bcast(c0.x, j); ey[k] = bw_bcast(c0.y, j);
+                eA[k] = bw_bcast(c0.z, j); eB[k] = bw_bcast(c0.w, j);
+                eC[k] = bw_bcast(c1.x, j);
+                const float o = bw_bcast(c1.y, j);
+                eo[k] = have ? o : 0.f;  // opacity 0 -> alpha 0 -> never hits
+                er[k] = bw_bcast(c1.z, j); eg[k] = bw_bcast(c1.w, j); eb[k] = bw_bcast(c2.x, j);
+                eid[k] = (uint32_t)__builtin_amdgcn_readlane((int)id_cur, j);
+                ef[k] = (uint32_t)(hi - 1 - j);  // 0-based position of the entry in the tile list
             }
             float dxs[BGRP], dys[BGRP], Gs[BGRP], alphas[BGRP];
             bool hits[BGRP];
             bool any_lane_hit = false;
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
-                // 0-based index of this entry from the list front; the null entry (slot BRB) wraps to a huge value
-                const uint32_t f = (uint32_t)(total - 1 - base) - ci[k];
-                const float dx = cur[k].q0.x - pixf_x, dy = cur[k].q0.y - pixf_y;
-                const float power = -0.5f * (cur[k].q0.z * dx * dx + cur[k].q1.x * dy * dy) - cur[k].q0.w * dx * dy;
-                const float G = expf(power);
-                const float alpha = fminf(0.99f, cur[k].q1.y * G);
+                const float dx = ex[k] - pixf_x, dy = ey[k] - pixf_y;
+                const float power = -0.5f * (eA[k] * dx * dx + eC[k] * dy * dy) - eB[k] * dx * dy;
+                const float G = bw_exp_nonpos(power);
+                const float alpha = fminf(0.99f, eo[k] * G);
                 dxs[k] = dx; dys[k] = dy; Gs[k] = G; alphas[k] = alpha;
-                hits[k] = (f < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                hits[k] = (ef[k] < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 any_lane_hit = any_lane_hit || hits[k];
             }
-            if (__any(any_lane_hit)) {
-                // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.  Only T,
-                // accum_rec, last_color and last_alpha are serial; a lane that does not hit multiplies T by 1 and
-                // keeps its state (selects), so the four steps are a short dependent chain the scheduler can
-                // overlap with phase 2 of the same group.
-                float dLa[BGRP], Gh[BGRP], dch[BGRP];
-#pragma unroll
-                for (int k = 0; k < BGRP; k++) {
-                    const bool hit = hits[k];
-                    const float alpha = alphas[k];
-                    const float4 col = cur[k].col;
-                    // The reference's two divisions by (1 - alpha) share one reciprocal here (gradients are compared
-                    // to tolerance, not bit-for-bit: the accumulation order differs anyway).
-                    const float rcp = 1.0f / (1.f - alpha);
-                    const float Tn = T * (hit ? rcp : 1.0f);
-                    const float om = 1.f - last_alpha;
-                    const float r0 = last_alpha * lc0 + om * acc_r0;
-                    const float r1 = last_alpha * lc1 + om * acc_r1;
-                    const float r2 = last_alpha * lc2 + om * acc_r2;
-                    float dL_dalpha = (col.x - r0) * dpx0;
-                    dL_dalpha += (col.y - r1) * dpx1;
-                    dL_dalpha += (col.z - r2) * dpx2;
-                    dL_dalpha *= Tn;
-                    dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
-                    // lanes that do not hit contribute exact zeros: three selects zero every product of phase 2
-                    dLa[k] = hit ? dL_dalpha : 0.f;
-                    Gh[k] = hit ? Gs[k] : 0.f;
-                    dch[k] = hit ? alpha * Tn : 0.f;
-                    T = Tn;
-                    acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
-                    lc0 = hit ? col.x : lc0; lc1 = hit ? col.y : lc1; lc2 = hit ? col.z : lc2;
-                    last_alpha = hit ? alpha : last_alpha;
-                }
-                // Phase 2: per entry, the nine partial derivatives, wave reduction, LDS accumulation.
-#pragma unroll
-                for (int k = 0; k < BGRP; k++) {
-                    if (!__any(hits[k])) continue;  // wave-uniform
-                    const float dx = dxs[k], dy = dys[k];
-                    const float4 q0 = cur[k].q0;
-                    const float2 q1 = cur[k].q1;
-                    const float dL_dG = q1.y * dLa[k];
-                    const float gdx = Gh[k] * dx, gdy = Gh[k] * dy;
-                    const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-                    const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-                    float g[NACC];
-                    g[0] = dL_dG * dG_ddelx * ddelx_dx;
-                    g[1] = dL_dG * dG_ddely * ddely_dy;
-                    g[2] = -0.5f * gdx * dx * dL_dG;
-                    g[3] = -0.5f * gdx * dy * dL_dG;
-                    g[4] = -0.5f * gdy * dy * dL_dG;
-                    g[5] = Gh[k] * dLa[k];
-                    g[6] = dch[k] * dpx0;
-                    g[7] = dch[k] * dpx1;
-                    g[8] = dch[k] * dpx2;
-#pragma unroll
-                    for (int c = 0; c < NACC; c++) g[c] = wave_sum_to_lane63(g[c]);
-                    if (lane == 63) {
-#pragma unroll
-                        for (int c = 0; c < NACC; c++) atomicAdd(&s_acc[ci[k]][c], g[c]);
-                    }
-                }
-            }
+            if (!__any(any_lane_hit)) continue;
+
+            // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.  A lane that does not
+            // hit multiplies T by exactly 1 and keeps its state.
+            float dLa[BGRP], Gh[BGRP], dch[BGRP];
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
-                cur[k] = nxt[k];
-                ci[k] = ni[k];
+                const bool hit = hits[k];
+                const float alpha = alphas[k];
+                const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = T * (hit ? rcp : 1.0f);
+                const float om = 1.f - last_alpha;
+                const float r0 = last_alpha * lc0 + om * acc_r0;
+                const float r1 = last_alpha * lc1 + om * acc_r1;
+                const float r2 = last_alpha * lc2 + om * acc_r2;
+                float dL_dalpha = (er[k] - r0) * dpx0;
+                dL_dalpha += (eg[k] - r1) * dpx1;
+                dL_dalpha += (eb[k] - r2) * dpx2;
+                dL_dalpha *= Tn;
+                dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
+                // lanes that do not hit contribute exact zeros: three selects zero every product of phase 2
+                dLa[k] = hit ? dL_dalpha : 0.f;
+                Gh[k] = hit ? Gs[k] : 0.f;
+                dch[k] = hit ? alpha * Tn : 0.f;
+                T = Tn;
+                acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
+                lc0 = hit ? er[k] : lc0; lc1 = hit ? eg[k] : lc1; lc2 = hit ? eb[k] : lc2;
+                last_alpha = hit ? alpha : last_alpha;
             }
+            // Phase 2: the 4 x 9 partial derivatives of this lane's pixel
+            float v[32], xo[BGRP];
+#pragma unroll
+            for (int k = 0; k < BGRP; k++) {
+                const float dx = dxs[k], dy = dys[k];
+                const float dL_dG = eo[k] * dLa[k];
+                const float gdx = Gh[k] * dx, gdy = Gh[k] * dy;
+                const float dG_ddelx = -gdx * eA[k] - gdy * eB[k];
+                const float dG_ddely = -gdy * eC[k] - gdx * eB[k];
+                v[8 * k + 0] = dL_dG * dG_ddelx * ddelx_dx;
+                v[8 * k + 1] = dL_dG * dG_ddely * ddely_dy;
+                v[8 * k + 2] = -0.5f * gdx * dx * dL_dG;
+                v[8 * k + 3] = -0.5f * gdx * dy * dL_dG;
+                v[8 * k + 4] = -0.5f * gdy * dy * dL_dG;
+                v[8 * k + 5] = dch[k] * dpx0;
+                v[8 * k + 6] = dch[k] * dpx1;
+                v[8 * k + 7] = dch[k] * dpx2;
+                xo[k] = Gh[k] * dLa[k];
+            }
+            // reduce over the 64 pixels, then one atomic instruction for the whole group
+            const float w = reduce32_transposed(v, lane);
+            const float z = reduce4_rows(xo[0], xo[1], xo[2], xo[3]);
+            const float val = (lane & 1u) ? z : w;
+            uint32_t id = eid[0];
+            id = tgt_k == 1 ? eid[1] : id;
+            id = tgt_k == 2 ? eid[2] : id;
+            id = tgt_k == 3 ? eid[3] : id;
+            if (tgt_on && val != 0.f) atomicAdd(reinterpret_cast<float*>(tgt_base + (size_t)id * tgt_stride), val);
         }
-        __syncthreads();
-
-        if ((int)tid < n) {
-            const uint32_t id = s_id[tid];
-            const float* r = s_acc[tid];
-            if (r[0] != 0.f) atomicAdd(a.dL_dmean2D + 3 * (size_t)id + 0, r[0]);
-            if (r[1] != 0.f) atomicAdd(a.dL_dmean2D + 3 * (size_t)id + 1, r[1]);
-            if (r[2] != 0.f) atomicAdd(a.dL_dconic + 4 * (size_t)id + 0, r[2]);
-            if (r[3] != 0.f) atomicAdd(a.dL_dconic + 4 * (size_t)id + 1, r[3]);
-            if (r[4] != 0.f) atomicAdd(a.dL_dconic + 4 * (size_t)id + 3, r[4]);
-            if (r[5] != 0.f) atomicAdd(a.dL_dopacity + (size_t)id, r[5]);
-            if (r[6] != 0.f) atomicAdd(a.dL_dcolor + 3 * (size_t)id + 0, r[6]);
-            if (r[7] != 0.f) atomicAdd(a.dL_dcolor + 3 * (size_t)id + 1, r[7]);
-            if (r[8] != 0.f) atomicAdd(a.dL_dcolor + 3 * (size_t)id + 2, r[8]);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        a.tile_clock[4 * tile + 2] = clk0;
-        a.tile_clock[4 * tile + 3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(id_nn)::"memory");
+        c0 = n0; c1 = n1; c2 = n2;
+        id_cur = id_nxt;
+        id_nxt = id_nn;
     }
 }
 
@@ -312,11 +380,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView&
     a.dL_dconic = dL_dconic;
     a.dL_dopacity = dL_dopacity;
     a.dL_dcolor = dL_dcolor;
-    a.tile_clock = iv.tile_clock;
-    // experiment knob: extra (unused) dynamic LDS caps how many tiles are resident per CU, which turns the
-    // hardware dispatcher into a longest-first dynamic scheduler
-    static const int lds_pad = getenv("GSR_RENDER_LDS_PAD") ? atoi(getenv("GSR_RENDER_LDS_PAD")) : 0;
-    hipLaunchKernelGGL(k_render_backward, dim3(a.gridx * gridy), dim3(256), lds_pad, L.stream, a);
+    hipLaunchKernelGGL(k_render_backward, dim3(4 * a.gridx * gridy), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_backward");
 }
 

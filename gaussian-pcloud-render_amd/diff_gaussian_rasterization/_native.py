@@ -32,7 +32,7 @@ class GsrParams(C.Structure):
 # every symbol include/gsr.h declares (tests check the library exports all of them)
 SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_stage1", "gsr_forward_stage2",
            "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling", "gsr_get_profile", "gsr_last_error",
-           "gsr_version")
+           "gsr_version", "gsr_selftest")
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
          FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, TILE_CLOCK=13)
@@ -67,6 +67,8 @@ def _load():
     lib.gsr_set_profiling.argtypes = [C.c_int]
     lib.gsr_get_profile.restype = C.c_int
     lib.gsr_get_profile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.gsr_selftest.restype = C.c_int
+    lib.gsr_selftest.argtypes = [_fp]
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
     return lib
@@ -239,6 +241,11 @@ def query(name, P, W, H, R, geom, binning, img):
         _check(lib.gsr_query(C.byref(p), Q[name], geom.data_ptr(), _ptr(binning), img.data_ptr(), int(R), out.data_ptr(),
                              out.numel() * out.element_size(), torch.cuda.current_stream(geom.device).cuda_stream))
     return out
+
+
+def selftest(device):
+    with torch.cuda.device(device):
+        _check(lib.gsr_selftest(torch.cuda.current_stream(device).cuda_stream))
 
 
 def set_profiling(on):

@@ -139,3 +139,9 @@ def test_determinism_of_forward(gpu_device):
     b, _ = util.run_product(s, gpu_device)
     assert a["out_color"].tobytes() == b["out_color"].tobytes()
     np.testing.assert_array_equal(a["vals"], b["vals"])
+
+
+def test_library_selftest_of_internal_primitives(gpu_device):
+    """Transposed wave64 reduction (v_permlane swaps + DPP) and the stable radix sort vs std::stable_sort."""
+    from diff_gaussian_rasterization import _native as N
+    N.selftest(gpu_device)
