@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "1")),
+                    help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,25 +92,31 @@ def main():
 
     grad = not args.forward_only
     leaf = lambda a: torch.from_numpy(a).to(dev).requires_grad_(grad)  # noqa: E731
-    means3D, shs, opac = leaf(g["means3D"]), leaf(g["shs"]), leaf(g["opacities"])
-    scales, rots = leaf(g["scales"]), leaf(g["rotations"])
-    means2D = torch.zeros_like(means3D, requires_grad=grad)
-    leaves = [means3D, means2D, shs, opac, scales, rots]
+
+    def make_leaves():
+        m3 = leaf(g["means3D"])
+        return dict(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=grad), shs=leaf(g["shs"]),
+                    opacities=leaf(g["opacities"]), scales=leaf(g["scales"]), rotations=leaf(g["rotations"]))
+
+    # one set of leaf tensors per host thread (their .grad is written by that thread's backward only)
+    leafsets = [make_leaves() for _ in range(max(1, args.streams))]
+    means3D, shs, opac = leafsets[0]["means3D"], leafsets[0]["shs"], leafsets[0]["opacities"]
+    scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
     gather_list = [torch.empty((3, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def step(i):
+    def step(i, tslot=0):
         v = (i * world + rank) % n_views
+        L = leafsets[tslot]
         if grad:
-            img, _ = rasterizers[v](means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+            img, _ = rasterizers[v](**L)
             (img * G).sum().backward()
-            for t in leaves:
+            for t in L.values():
                 t.grad = None
             img = img.detach()
         else:
             with torch.no_grad():
-                img, _ = rasterizers[v](means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales,
-                                        rotations=rots)
+                img, _ = rasterizers[v](**L)
         if world > 1 and not args.no_gather:
             dist.gather(img, gather_list=gather_list, dst=0)
         return v
@@ -119,17 +127,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    import threading
+
+    def run_steps(first, count):
+        """`count` steps starting at global step index `first`, spread over --streams host threads / HIP streams."""
+        if args.streams <= 1:
+            for i in range(first, first + count):
+                step(i)
+            return
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        errs = []
+
+        def worker(t):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[t]):
+                    for i in range(first + t, first + count, args.streams):
+                        step(i, t)
+                streams[t].synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        cur = torch.cuda.current_stream(dev)
+        for st in streams:
+            st.wait_stream(cur)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(args.streams)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+
+    run_steps(0, args.warmup)
     fence()
-    _native.set_profiling(rank == 0)
+    _native.set_profiling(rank == 0 and args.streams <= 1)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     prof = _native.get_profile() if rank == 0 else []
     _native.set_profiling(False)
+    kernel_timing = "hipEvents on the launch stream over the timed region"
+    if rank == 0 and args.streams > 1:
+        # with several streams in flight the per-stage events overlap; time the stages in a single-stream pass instead
+        _native.set_profiling(True)
+        for i in range(min(args.steps, 12)):
+            step(args.warmup + i * world)
+        torch.cuda.synchronize()
+        prof = _native.get_profile()
+        _native.set_profiling(False)
+        kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % min(args.steps, 12)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,7 +252,8 @@ def main():
                 "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+            "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()}, "kernel_timing": kernel_timing,
+            "streams_per_rank": args.streams,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
                           "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
         }

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         tgt_stride = 4;
     }
 
-    float acc_r0 = 0.f, acc_r1 = 0.f, acc_r2 = 0.f;           // accum_rec
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last_color
+    float s_rec = 0.f;                        // accum_rec . dL_dpixel
+    float last_alpha = 0.f, last_d = 0.f;     // last alpha, last_color . dL_dpixel
 
     const uint32_t* plist = a.point_list + range.x;
     // Round r covers front indices hi-64 .. hi-1 (hi = total - 64 r), lane i <-> f = hi-1-i, so the lowest set bit of
@@ -299,6 +299,11 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 
             // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.  A lane that does not
             // hit multiplies T by exactly 1 and keeps its state.
+            // The reference tracks accum_rec[ch], the colour accumulated behind the current entry, only to form
+            // sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  That sum is linear, so the same recurrence is run on the
+            // scalar s = accum_rec . dL_dpixel and d = c . dL_dpixel (7 operations per entry instead of 18); fused
+            // multiply-adds are allowed from here on (gradients are compared to tolerance; power / alpha above are not
+            // touched, so hit decisions stay those of the forward pass).
             float dLa[BGRP], Gh[BGRP], dch[BGRP];
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
@@ -306,22 +311,17 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 const float alpha = alphas[k];
                 const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T * (hit ? rcp : 1.0f);
-                const float om = 1.f - last_alpha;
-                const float r0 = last_alpha * lc0 + om * acc_r0;
-                const float r1 = last_alpha * lc1 + om * acc_r1;
-                const float r2 = last_alpha * lc2 + om * acc_r2;
-                float dL_dalpha = (er[k] - r0) * dpx0;
-                dL_dalpha += (eg[k] - r1) * dpx1;
-                dL_dalpha += (eb[k] - r2) * dpx2;
-                dL_dalpha *= Tn;
-                dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
+                const float d = __builtin_fmaf(eb[k], dpx2, __builtin_fmaf(eg[k], dpx1, er[k] * dpx0));
+                const float sn = __builtin_fmaf(last_alpha, last_d - s_rec, s_rec);  // la*last_d + (1-la)*s
+                float dL_dalpha = (d - sn) * Tn;
+                dL_dalpha = __builtin_fmaf(-T_final * rcp, bg_dot_dpixel, dL_dalpha);
                 // lanes that do not hit contribute exact zeros: three selects zero every product of phase 2
                 dLa[k] = hit ? dL_dalpha : 0.f;
                 Gh[k] = hit ? Gs[k] : 0.f;
                 dch[k] = hit ? alpha * Tn : 0.f;
                 T = Tn;
-                acc_r0 = hit ? r0 : acc_r0; acc_r1 = hit ? r1 : acc_r1; acc_r2 = hit ? r2 : acc_r2;
-                lc0 = hit ? er[k] : lc0; lc1 = hit ? eg[k] : lc1; lc2 = hit ? eb[k] : lc2;
+                s_rec = hit ? sn : s_rec;
+                last_d = hit ? d : last_d;
                 last_alpha = hit ? alpha : last_alpha;
             }
             // Phase 2: the 4 x 9 partial derivatives of this lane's pixel
@@ -331,13 +331,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 const float dx = dxs[k], dy = dys[k];
                 const float dL_dG = eo[k] * dLa[k];
                 const float gdx = Gh[k] * dx, gdy = Gh[k] * dy;
-                const float dG_ddelx = -gdx * eA[k] - gdy * eB[k];
-                const float dG_ddely = -gdy * eC[k] - gdx * eB[k];
+                const float dG_ddelx = -__builtin_fmaf(gdx, eA[k], gdy * eB[k]);
+                const float dG_ddely = -__builtin_fmaf(gdy, eC[k], gdx * eB[k]);
+                const float h = -0.5f * dL_dG;
                 v[8 * k + 0] = dL_dG * dG_ddelx * ddelx_dx;
                 v[8 * k + 1] = dL_dG * dG_ddely * ddely_dy;
-                v[8 * k + 2] = -0.5f * gdx * dx * dL_dG;
-                v[8 * k + 3] = -0.5f * gdx * dy * dL_dG;
-                v[8 * k + 4] = -0.5f * gdy * dy * dL_dG;
+                v[8 * k + 2] = h * gdx * dx;
+                v[8 * k + 3] = h * gdx * dy;
+                v[8 * k + 4] = h * gdy * dy;
                 v[8 * k + 5] = dch[k] * dpx0;
                 v[8 * k + 6] = dch[k] * dpx1;
                 v[8 * k + 7] = dch[k] * dpx2;
