@@ -7,6 +7,10 @@ Workload (BASELINE.json metric, configs[2]): synth-THuman-800K -- 
 `circle` cameras, forward + backward through the public GaussianRasterizer API, loss = sum(img * G).
 A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered on
 rank 0 with RCCL (weak scaling).  All inputs are resident in HBM before the timed region.
+Views are independent, so each rank keeps --streams (default 4) frames in flight: that many host threads, each
+rendering whole frames (forward + backward) on its own HIP stream; the tail of one frame's render kernels overlaps
+the bandwidth-bound stages of the next.  The single-stream rate and the per-stage timings are measured in a second,
+single-stream pass right after the timed region and reported next to the headline value.
 
 Prints ONE JSON line on rank 0 with the throughput plus
   roofline     -- the dominant kernel's algorithmic bytes / its measured duration (hipEvents on the launch stream)
@@ -49,8 +53,8 @@ def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--workload", default="synth-THuman-800K")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -59,7 +63,7 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "4")),
                     help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
     args = ap.parse_args()
 
@@ -105,7 +109,10 @@ def main():
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
     gather_list = [torch.empty((3, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def step(i, tslot=0):
+    do_gather = world > 1 and not args.no_gather
+
+    def render(i, tslot=0):
+        """Forward (+ backward) of global step i on the calling thread's current stream; returns the frame."""
         v = (i * world + rank) % n_views
         L = leafsets[tslot]
         if grad:
@@ -113,13 +120,18 @@ def main():
             (img * G).sum().backward()
             for t in L.values():
                 t.grad = None
-            img = img.detach()
-        else:
-            with torch.no_grad():
-                img, _ = rasterizers[v](**L)
-        if world > 1 and not args.no_gather:
-            dist.gather(img, gather_list=gather_list, dst=0)
-        return v
+            return img.detach()
+        with torch.no_grad():
+            img, _ = rasterizers[v](**L)
+        return img
+
+    def gather(img):
+        dist.gather(img, gather_list=gather_list, dst=0)
+
+    def step(i, tslot=0):
+        img = render(i, tslot)
+        if do_gather:
+            gather(img)
 
     def fence():
         torch.cuda.synchronize()
@@ -127,57 +139,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import threading
-
     def run_steps(first, count):
-        """`count` steps starting at global step index `first`, spread over --streams host threads / HIP streams."""
-        if args.streams <= 1:
-            for i in range(first, first + count):
-                step(i)
-            return
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
-        errs = []
+        """`count` steps from global step `first`: --streams frames in flight (pcrender.multiview.run_frames_pipelined);
+        the frame gather is issued by this thread only, in step order, so every rank enqueues collectives identically."""
+        multiview.run_frames_pipelined(render, first, count, args.streams,
+                                       on_frame=(lambda i, img: gather(img)) if do_gather else None, device=dev)
 
-        def worker(t):
-            try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(streams[t]):
-                    for i in range(first + t, first + count, args.streams):
-                        step(i, t)
-                streams[t].synchronize()
-            except Exception as e:  # noqa: BLE001
-                errs.append(e)
-
-        cur = torch.cuda.current_stream(dev)
-        for st in streams:
-            st.wait_stream(cur)
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(args.streams)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if errs:
-            raise errs[0]
-
-    run_steps(0, args.warmup)
+    # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
+    # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing
+    warm = max(args.warmup, 3 * max(1, args.streams))
+    for i in range(3):
+        step(i)
+    run_steps(0, warm)
     fence()
     _native.set_profiling(rank == 0 and args.streams <= 1)
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    run_steps(warm, args.steps)
     fence()
     dt = time.perf_counter() - t0
     prof = _native.get_profile() if rank == 0 else []
     _native.set_profiling(False)
     kernel_timing = "hipEvents on the launch stream over the timed region"
+    single = None
     if rank == 0 and args.streams > 1:
         # with several streams in flight the per-stage events overlap; time the stages in a single-stream pass instead
-        _native.set_profiling(True)
-        for i in range(min(args.steps, 12)):
-            step(args.warmup + i * world)
+        n1 = min(args.steps, 24)
         torch.cuda.synchronize()
+        _native.set_profiling(True)
+        t1 = time.perf_counter()
+        for i in range(n1):
+            step(warm + i)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
         prof = _native.get_profile()
         _native.set_profiling(False)
-        kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % min(args.steps, 12)
+        single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1}
+        kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % n1
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,7 +182,7 @@ def main():
 
     if rank == 0:
         # ---- workload statistics for the bytes model, averaged over the views rank 0 rendered
-        used = sorted({((args.warmup + i) * world) % n_views for i in range(args.steps)})
+        used = sorted({((warm + i) * world) % n_views for i in range(args.steps)})
         stats = dict(V=0.0, R=0.0, C_fwd=0.0, C_bwd=0.0)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         with torch.no_grad():
@@ -212,10 +209,17 @@ def main():
         avg_ms = {k: float(np.mean(v)) for k, v in ms.items()}
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
         roofline = None
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KiB -> B)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get("bytes_per_launch", {}).get({"render_backward": "k_render_backward",
+                                                                          "render_forward": "k_render_forward"}.get(dom, dom))
+        except (OSError, ValueError):
+            traffic = None
         if dom is not None:
             achieved = bytes_per[dom] / (avg_ms[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes": int(bytes_per[dom]), "avg_ms": round(avg_ms[dom], 4)}
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
         frame_gpu_ms = sum(avg_ms.values())
@@ -243,7 +247,7 @@ def main():
             "metric": "rendered frames/sec at 1080p (fwd+bwd), THuman-800K" if (grad and (W, H) == (1920, 1080)) else
                       "rendered frames/sec %dx%d (%s)" % (W, H, "fwd+bwd" if grad else "fwd"),
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "warmup_effective": warm + 3, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d), view-sharded%s" % (
                 args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M,
@@ -253,7 +257,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()}, "kernel_timing": kernel_timing,
-            "streams_per_rank": args.streams,
+            "streams_per_rank": args.streams, "single_stream": single,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
                           "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
         }

@@ -73,6 +73,24 @@ __device__ __forceinline__ float exp_nonpos(float x)
     return __builtin_ldexpf(r, (int)e);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two-entry version: the multiplies / fused multiply-adds / adds become packed fp32 instructions (v_pk_*_f32, two
+// IEEE operations per lane per issue slot); rounding per component is that of exp_nonpos
+__device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x)
+{
+    const f32x2 c = {0x1.715476p+0f, 0x1.715476p+0f}, cc = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+    const f32x2 ph = x * c;
+    f32x2 pl = __builtin_elementwise_fma(x, c, -ph);
+    pl = __builtin_elementwise_fma(x, cc, pl);
+    const f32x2 e = {__builtin_rintf(ph.x), __builtin_rintf(ph.y)};
+    const f32x2 a = (ph - e) + pl;
+    f32x2 r;
+    r.x = __builtin_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)e.x);
+    r.y = __builtin_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)e.y);
+    return r;
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
@@ -94,7 +112,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     const int total = (int)(range.y - range.x);
 
     float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    f32x2 C01 = {0.f, 0.f};
+    float C2 = 0.f;
     uint32_t last_contributor = 0;
     uint32_t stop_at = 0;  // 1-based index of the entry that terminated this pixel
     bool done = !inside;
@@ -151,16 +170,23 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                     er[k] = lane_bcast(c1.z, j); eg[k] = lane_bcast(c1.w, j); eb[k] = lane_bcast(c2.x, j);
                     eidx[k] = (uint32_t)(base + j + 1);  // 1-based position in the tile list
                 }
-                // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0
+                // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  Entries are taken in
+                // pairs so the arithmetic maps onto packed fp32 instructions (this kernel is VALU-issue bound).
                 float alpha[GRP], ae[GRP];
                 bool cnt[GRP];
 #pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    const float dx = ex[k] - pixf_x, dy = ey[k] - pixf_y;
-                    const float power = -0.5f * (eA[k] * dx * dx + eC[k] * dy * dy) - eB[k] * dx * dy;
-                    alpha[k] = fminf(0.99f, eo[k] * exp_nonpos(power));
-                    cnt[k] = !done && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+                for (int k = 0; k < GRP; k += 2) {
+                    const f32x2 X = {ex[k], ex[k + 1]}, Y = {ey[k], ey[k + 1]}, A2 = {eA[k], eA[k + 1]};
+                    const f32x2 B2 = {eB[k], eB[k + 1]}, C2 = {eC[k], eC[k + 1]}, O2 = {eo[k], eo[k + 1]};
+                    const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
+                    const f32x2 power = -0.5f * (A2 * dx * dx + C2 * dy * dy) - B2 * dx * dy;
+                    const f32x2 al = O2 * exp_nonpos2(power);
+                    alpha[k] = fminf(0.99f, al.x);
+                    alpha[k + 1] = fminf(0.99f, al.y);
+                    cnt[k] = !done && !(power.x > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+                    cnt[k + 1] = !done && !(power.y > 0.0f) && !(alpha[k + 1] < 1.0f / 255.0f);
                     ae[k] = cnt[k] ? alpha[k] : 0.f;
+                    ae[k + 1] = cnt[k + 1] ? alpha[k + 1] : 0.f;
                 }
                 // Optimistic pass: assume no pixel of this wave terminates inside the group.  T then only needs the
                 // products T*(1-ae) (ae = 0 multiplies by exactly 1), and because T never increases and every live
@@ -174,8 +200,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 #pragma unroll
                     for (int k = 0; k < GRP; k++) {
                         // ae = 0 adds a zero, which leaves C unchanged bit-for-bit (C is never -0)
-                        C0 += er[k] * ae[k] * Tk[k];
-                        C1 += eg[k] * ae[k] * Tk[k];
+                        const f32x2 rg = {er[k], eg[k]};
+                        C01 += rg * ae[k] * Tk[k];
                         C2 += eb[k] * ae[k] * Tk[k];
                         last_contributor = cnt[k] ? eidx[k] : last_contributor;
                     }
@@ -187,8 +213,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         const bool hit = !done && cnt[k];
                         const bool stop = hit && (test_T < 0.0001f);
                         const bool blend = hit && !stop;
-                        C0 += blend ? er[k] * alpha[k] * T : 0.f;
-                        C1 += blend ? eg[k] * alpha[k] * T : 0.f;
+                        C01.x += blend ? er[k] * alpha[k] * T : 0.f;
+                        C01.y += blend ? eg[k] * alpha[k] * T : 0.f;
                         C2 += blend ? eb[k] * alpha[k] * T : 0.f;
                         T = blend ? test_T : T;
                         last_contributor = blend ? eidx[k] : last_contributor;
@@ -221,8 +247,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
         a.final_T[pix] = T;
         a.n_contrib[pix] = last_contributor;
-        a.out_color[pix] = C0 + T * a.bg[0];
-        a.out_color[N + pix] = C1 + T * a.bg[1];
+        a.out_color[pix] = C01.x + T * a.bg[0];
+        a.out_color[N + pix] = C01.y + T * a.bg[1];
         a.out_color[2 * N + pix] = C2 + T * a.bg[2];
     }
 }

@@ -64,3 +64,81 @@ def render_views(render_one, n_views, dst=0, group=None):
     if not frames:
         raise ValueError("rank %d owns no view (n_views=%d < world=%d)" % (rank, n_views, world))
     return gather_frames(torch.stack(frames, 0), n_views, dst=dst, group=group)
+
+
+def run_frames_pipelined(render, first, count, n_inflight, on_frame=None, device=None):
+    """Keep `n_inflight` independent frames in flight on one GPU.
+
+    `render(step, slot) -> tensor` renders one whole frame (forward, and backward if the caller wants) on the
+    calling thread's current stream; `slot` in [0, n_inflight) names the worker so the caller can give every worker
+    its own leaf tensors.  Frames are independent (views of one cloud), so `n_inflight` host threads each render
+    every n_inflight-th step on their own HIP stream: one frame's tail overlaps the next frame's bandwidth-bound
+    stages (ctypes releases the GIL during the native calls, including the one stream sync per frame).
+
+    `on_frame(step, tensor)`, if given, is called on the CALLING thread, in increasing step order, after making the
+    caller's stream wait for the frame - this is where collectives (the frame gather) belong, so that every rank
+    issues them in the same order whatever the thread timing.  With device=None (CPU tests) no streams are used.
+    """
+    import threading
+
+    if n_inflight <= 1:
+        for i in range(first, first + count):
+            img = render(i, 0)
+            if on_frame is not None:
+                on_frame(i, img)
+        return
+    use_cuda = device is not None and torch.device(device).type == "cuda"
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)] if use_cuda else [None] * n_inflight
+    errs = []
+    ready = {i: threading.Event() for i in range(first, first + count)}
+    frames = {}
+
+    def worker(t):
+        try:
+            if use_cuda:
+                torch.cuda.set_device(device)
+            ctx = torch.cuda.stream(streams[t]) if use_cuda else _NullCtx()
+            with ctx:
+                for i in range(first + t, first + count, n_inflight):
+                    img = render(i, t)
+                    ev = None
+                    if use_cuda:
+                        ev = torch.cuda.Event()
+                        ev.record(streams[t])
+                    frames[i] = (img, ev)
+                    ready[i].set()
+            if use_cuda:
+                streams[t].synchronize()
+        except Exception as e:  # noqa: BLE001 - re-raised on the calling thread
+            errs.append(e)
+            for e2 in ready.values():
+                e2.set()
+
+    cur = torch.cuda.current_stream(device) if use_cuda else None
+    if use_cuda:
+        for st in streams:
+            st.wait_stream(cur)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_inflight)]
+    for x in threads:
+        x.start()
+    for i in range(first, first + count):
+        ready[i].wait()
+        if errs:
+            break
+        img, ev = frames.pop(i)
+        if on_frame is not None:
+            if ev is not None:
+                cur.wait_event(ev)
+            on_frame(i, img)
+    for x in threads:
+        x.join()
+    if errs:
+        raise errs[0]
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -77,3 +77,64 @@ def test_single_process_passthrough():
     assert out.shape == (4, 3, 6, 10) and torch.equal(out[2], _frame(2))
     with pytest.raises(ValueError):
         multiview.render_views(_frame, 0)
+
+
+def _pipe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcrender import multiview
+    try:
+        import time
+        got = []
+        bufs = [torch.empty(3, 6, 10) for _ in range(world)] if rank == 0 else None
+
+        def render(i, slot):
+            time.sleep(0.002 * ((i * 7 + rank * 3 + slot) % 5))   # scramble thread timing
+            return _frame(i * world + rank)
+
+        def on_frame(i, img):
+            dist.gather(img, gather_list=bufs, dst=0)
+            if rank == 0:
+                got.append((i, [b.clone() for b in bufs]))
+
+        multiview.run_frames_pipelined(render, 3, 10, 4, on_frame=on_frame, device=None)
+        ok = True
+        if rank == 0:
+            ok = [i for i, _ in got] == list(range(3, 13))
+            for i, fr in got:
+                for r in range(world):
+                    ok = ok and torch.equal(fr[r], _frame(i * world + r))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_frames_gather_in_step_order_world2():
+    """4 frames in flight per rank (threads), gathers issued in step order by the main thread: every rank's k-th
+    collective carries the same step, so frames never mix across steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, 29633, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_pipelined_frames_propagate_errors():
+    from pcrender import multiview
+
+    def render(i, slot):
+        if i == 5:
+            raise RuntimeError("boom")
+        return torch.zeros(1)
+
+    with pytest.raises(RuntimeError, match="boom"):
+        multiview.run_frames_pipelined(render, 0, 12, 3, on_frame=lambda i, t: None, device=None)
+    seen = []
+    multiview.run_frames_pipelined(lambda i, s: torch.full((1,), float(i)), 0, 7, 3, on_frame=lambda i, t: seen.append(int(t)))
+    assert seen == list(range(7))
