@@ -31,7 +31,7 @@ struct RenderArgs {
     const uint32_t* tile_order;
     const uint32_t* point_list;
     const Splat* splat;
-    int W, H, gridx;
+    int W, H, gridx, num_tiles;
     const float* bg;
     float* out_color;
     float* final_T;
@@ -98,8 +98,13 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 
 __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 {
-    const uint32_t tile = a.tile_order[blockIdx.x >> 2];
-    const uint32_t q = blockIdx.x & 3u;
+    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
+    // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
+    // are fetched into that L2 once instead of four times.
+    const uint32_t order_slot = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
+    if (order_slot >= (uint32_t)a.num_tiles) return;
+    const uint32_t tile = a.tile_order[order_slot];
+    const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
     const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
@@ -271,7 +276,8 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& 
     a.tile_need = iv.tile_need;
     const int T = a.gridx * gridy;
     if (hipMemsetAsync(iv.tile_need, 0, (size_t)T * sizeof(uint32_t), L.stream) != hipSuccess) return GSR_ERR_HIP;
-    hipLaunchKernelGGL(k_render_forward, dim3(4 * T), dim3(64), 0, L.stream, a);
+    a.num_tiles = T;
+    hipLaunchKernelGGL(k_render_forward, dim3((unsigned)div_up(T, 8) * 32u), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_forward");
 }
 
