@@ -156,6 +156,10 @@ int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void*
         hipStreamSynchronize(L.stream) != hipSuccess)
         return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
     if (host[1]) return fail(GSR_ERR_TRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    // the reference keeps num_rendered in an int (CR/rasterizer_impl.cu:280); beyond that its arena sizes wrap
+    if (host[0] > 0x7FFFFFFFull)
+        return fail(GSR_ERR_CAPACITY, "[gsr] num_rendered = %llu tile pairs does not fit the reference's int (scales too large?)",
+                    (unsigned long long)host[0]);
     *num_rendered_out = (int64_t)host[0];
     return GSR_OK;
 }

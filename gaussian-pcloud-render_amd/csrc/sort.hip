@@ -225,17 +225,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int P, const uint3
 __global__ __launch_bounds__(256) void k_scan_blocksums(uint32_t* __restrict__ block_sums, int nb,
                                                         uint64_t* __restrict__ total_out)
 {
-    __shared__ uint32_t tmp[4];
-    uint32_t carry = 0;
+    // 64-bit throughout: a hostile cloud (huge scales) can touch P x T > 2^32 tiles; the host refuses such a frame,
+    // but it has to see the true total to do so.
+    __shared__ uint64_t tmp64[4];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t carry = 0;
     for (int b0 = 0; b0 < nb; b0 += 256) {
         const int b = b0 + threadIdx.x;
-        const uint32_t v = b < nb ? block_sums[b] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan_256(v, tmp, &tot);
-        if (b < nb) block_sums[b] = carry + ex;
+        const uint64_t v = b < nb ? (uint64_t)block_sums[b] : 0ull;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc, d, 64);
+            if (lane >= (uint32_t)d) inc += n;
+        }
+        if (lane == 63) tmp64[w] = inc;
+        __syncthreads();
+        uint64_t base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((uint32_t)i < w) base += tmp64[i];
+        const uint64_t tot = tmp64[0] + tmp64[1] + tmp64[2] + tmp64[3];
+        __syncthreads();
+        if (b < nb) block_sums[b] = (uint32_t)(carry + base + inc - v);  // offsets are only used when the total fits
         carry += tot;
     }
-    if (threadIdx.x == 0) total_out[0] = (uint64_t)carry;
+    if (threadIdx.x == 0) total_out[0] = carry;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int P, const uint32_t* __restrict__ order,

@@ -145,3 +145,37 @@ def test_library_selftest_of_internal_primitives(gpu_device):
     """Transposed wave64 reduction (v_permlane swaps + DPP) and the stable radix sort vs std::stable_sort."""
     from diff_gaussian_rasterization import _native as N
     N.selftest(gpu_device)
+
+
+def test_hostile_inputs_fail_cleanly_or_render_finite(gpu_device):
+    """Huge scales (every Gaussian touches every tile), zero / negative opacity, negative colours, NaN means: no hang,
+    no out-of-bounds; either a clean error or a finite image for the finite part of the input."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = gpu_device
+    s = build_scene("random_aniso")
+    st = _settings(s, dev)
+    m = torch.from_numpy(s.means3D).to(dev)
+    sh, op = torch.from_numpy(s.shs).to(dev), torch.from_numpy(s.opacities).to(dev).reshape(-1, 1)
+    sc, ro = torch.from_numpy(s.scales).to(dev), torch.from_numpy(s.rotations).to(dev)
+    with torch.no_grad():
+        # every Gaussian covers the whole (small) image: R = P * T, lists of P entries per tile
+        img, radii = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), shs=sh, opacities=op * 0.05, scales=sc * 500, rotations=ro)
+        assert img.isfinite().all()
+        # opacity <= 0 never contributes: pure background
+        img, _ = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), shs=sh, opacities=-op, scales=sc, rotations=ro)
+        assert torch.equal(img, st.bg.reshape(3, 1, 1).expand_as(img))
+        # NaN means are dropped by the near-plane test of the reference only if z compares false; they must not hang
+        m2 = m.clone()
+        m2[::7] = float("nan")
+        img, radii = GaussianRasterizer(st)(means3D=m2, means2D=torch.zeros_like(m), shs=sh, opacities=op, scales=sc, rotations=ro)
+        torch.cuda.synchronize()
+        assert radii.shape == (s.P,)
+    # a 1080p frame where all 3000 Gaussians are gigantic overflows nothing (3000 * 8160 pairs) but is refused above 2^31
+    big = GaussianRasterizer(st._replace(image_height=8192, image_width=8192))
+    P = 20000
+    mm = torch.zeros((P, 3), device=dev)
+    mm[:, 2] = 1.0
+    with torch.no_grad(), pytest.raises(RuntimeError, match="does not fit the reference's int"):
+        big(means3D=mm, means2D=torch.zeros_like(mm), colors_precomp=torch.ones((P, 3), device=dev),
+            opacities=torch.ones((P, 1), device=dev), scales=torch.full((P, 3), 100.0, device=dev),
+            rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(P, 1))
