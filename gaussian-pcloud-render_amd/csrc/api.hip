@@ -206,6 +206,38 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
     return GSR_OK;
 }
 
+// Colour-only re-render on the geometry / lists of a finished forward (same P, view, image size).
+int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes, void* image,
+                        size_t image_bytes, int64_t R, float* out_color, gsr_stream_t stream)
+{
+    if (!p) return fail(GSR_ERR_INVALID, "[gsr] params is NULL");
+    if (p->P <= 0) return GSR_OK;
+    if ((p->shs == nullptr) == (p->colors_precomp == nullptr))
+        return fail(GSR_ERR_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
+    if (p->shs && (!p->means3D || !p->campos || p->D < 0 || p->D > 3 || (p->D + 1) * (p->D + 1) > p->M))
+        return fail(GSR_ERR_INVALID, "[gsr] recolor: bad SH arguments");
+    if (!out_color || !p->bg) return fail(GSR_ERR_INVALID, "[gsr] recolor: NULL pointer");
+    if (R < 0 || R > 0x7FFFFFFFll) return fail(GSR_ERR_INVALID, "[gsr] num_rendered out of range");
+    if (!geom || geom_bytes < gsr_geom_bytes(p->P) || !image || image_bytes < gsr_image_bytes(p->W, p->H) || !binning ||
+        binning_bytes < gsr_binning_bytes(R))
+        return fail(GSR_ERR_CAPACITY, "[gsr] an arena is too small for recolor");
+    const Launch L{(hipStream_t)stream, p->debug};
+    const GeomView g = geom_view(align256(geom), p->P);
+    const BinView b = bin_view(align256(const_cast<void*>(binning)), R);
+    const ImageView iv = image_view(align256(image), p->W, p->H);
+    const int passes = (tile_bits(tile_count(p)) + RADIX_BITS - 1) / RADIX_BITS;
+    const int res = R > 0 ? (passes & 1) : 0;
+    {
+        ProfScope ps("recolor", L.stream);
+        if (int e = launch_recolor(L, *p, g)) return e;
+    }
+    {
+        ProfScope ps("render_forward", L.stream);
+        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color)) return e;
+    }
+    return GSR_OK;
+}
+
 int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* geom, size_t geom_bytes, const void* binning,
                  size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,

@@ -161,6 +161,7 @@ int check_launch(const Launch& L, const char* what);  // api.hip
 
 // preprocess.hip
 int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, int* radii);
+int launch_recolor(const Launch& L, const gsr_params& p, const GeomView& g);
 int launch_mark_visible(const Launch& L, int P, const float* means3D, const float* view, uint8_t* present);
 // sort.hip
 int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32_t* val[2], bool iota_vals,

@@ -191,6 +191,40 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, i
     return check_launch(L, "preprocess");
 }
 
+// ---- colour-only update of the Splat records (gsr_forward_recolor) -----------------------------------------
+// The reference's caller renders four passes per view that differ only in the per-Gaussian colour (world xyz, SH
+// colour, ones = hit map, normals; /root/reference/simple_raw_render.py:410-524), each through the full pipeline.
+// Geometry, lists and ranges are identical across the passes, so a pass can reuse them: this kernel rewrites the three
+// colour floats of every visible Gaussian's record (precomputed colours verbatim, or the SH colour exactly as
+// k_preprocess computes it) and the caller re-launches the compositing kernel only.
+__global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const float* __restrict__ means3D,
+                                                 const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                                                 const float* __restrict__ campos, const uint32_t* __restrict__ tiles_touched,
+                                                 Splat* __restrict__ splat)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || tiles_touched[idx] == 0) return;
+    V3 rgb;
+    if (colors_precomp) {
+        rgb = v3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
+    } else {
+        uint32_t cmask;
+        const V3 pos = v3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        rgb = sh_to_rgb(D, pos, v3(campos[0], campos[1], campos[2]), shs + (size_t)idx * M * 3, &cmask);
+    }
+    float* rec = reinterpret_cast<float*>(splat + idx);
+    rec[6] = rgb.x;  // q1.z
+    rec[7] = rgb.y;  // q1.w
+    rec[8] = rgb.z;  // q2.x
+}
+
+int launch_recolor(const Launch& L, const gsr_params& p, const GeomView& g)
+{
+    hipLaunchKernelGGL(k_recolor, dim3((p.P + 255) / 256), dim3(256), 0, L.stream, p.P, p.D, p.M, p.means3D, p.shs,
+                       p.colors_precomp, p.campos, g.tiles_touched, g.splat);
+    return check_launch(L, "recolor");
+}
+
 // reference CR/rasterizer_impl.cu:54-66 (checkFrustum): only the near-plane test is live
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
                                                       const float* __restrict__ view, uint8_t* __restrict__ present)

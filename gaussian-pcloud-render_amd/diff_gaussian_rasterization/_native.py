@@ -32,7 +32,7 @@ class GsrParams(C.Structure):
 # every symbol include/gsr.h declares (tests check the library exports all of them)
 SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_stage1", "gsr_forward_stage2",
            "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling", "gsr_get_profile", "gsr_last_error",
-           "gsr_version", "gsr_selftest")
+           "gsr_version", "gsr_selftest", "gsr_forward_recolor")
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
          FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, TILE_CLOCK=13)
@@ -56,6 +56,8 @@ def _load():
     lib.gsr_forward_stage2.restype = C.c_int
     lib.gsr_forward_stage2.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
                                        C.c_int64, _fp, _fp]
+    lib.gsr_forward_recolor.restype = C.c_int
+    lib.gsr_forward_recolor.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, C.c_int64, _fp, _fp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_backward.argtypes = [C.POINTER(GsrParams), _fp, C.c_int64, _fp, C.c_size_t, _fp, C.c_size_t, _fp,
                                  C.c_size_t] + [_fp] * 10 + [_fp]
@@ -159,6 +161,28 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                       img.data_ptr(), img.numel(), R.value, out_color.data_ptr(), stream))
     del keep
     return int(R.value), out_color, radii, geom, binning, img
+
+
+def recolor(background, means3D, colors, sh, degree, campos, image_height, image_width, num_rendered, geomBuffer,
+            binningBuffer, imgBuffer, debug=False):
+    """Re-render a finished forward's view with other per-Gaussian colours (exactly one of `colors` [P,3] / `sh`
+    [P,M,3] non-empty), reusing its geometry, sorted lists and ranges (gsr_forward_recolor).  Returns color [3,H,W]."""
+    device = means3D.device
+    _require_hip(device)
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
+    if P == 0:
+        return out_color
+    with torch.cuda.device(device):
+        e = torch.empty(0)
+        p, keep = _params(background, means3D, colors, torch.empty((1,), device=device), e, e, 1.0, e,
+                          torch.empty((1,), device=device), torch.empty((1,), device=device), 1.0, 1.0, H, W, sh, degree,
+                          campos, False, debug, False)
+        _check(lib.gsr_forward_recolor(C.byref(p), geomBuffer.data_ptr(), geomBuffer.numel(), binningBuffer.data_ptr(),
+                                       binningBuffer.numel(), imgBuffer.data_ptr(), imgBuffer.numel(), int(num_rendered),
+                                       out_color.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+        del keep
+    return out_color
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

@@ -92,6 +92,16 @@ int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void*
 int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                        void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
 
+/* Colour-only re-render.  The reference's caller renders four passes per view that differ only in the
+ * per-Gaussian colour (world xyz / SH colour / ones / normals, simple_raw_render.py:410-524), each through the whole
+ * pipeline.  After a forward (stage1 + stage2) this entry re-renders the same view with other colours on the SAME
+ * geometry, lists and ranges: p->colors_precomp [P,3] (verbatim) or p->shs (evaluated like the forward does); only
+ * P, D, M, W, H, bg, means3D, shs / colors_precomp, campos of *p are read.  The result is bit-identical to a full
+ * forward with those colours.  The arenas stay valid for further recolor calls; a backward afterwards differentiates
+ * the LAST colours rendered. */
+int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                        void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
+
 /* Backward.  All dL_* outputs must be zero-filled by the caller (rasterize_points.cu:151-159);
  * shapes: dL_dmean2D[P,3] dL_dconic[P,2,2] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3]
  * dL_dcov3D[P,6] dL_dsh[P,M,3] dL_dscale[P,3] dL_drot[P,4]. */
