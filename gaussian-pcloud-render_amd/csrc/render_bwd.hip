@@ -54,6 +54,22 @@ __device__ __forceinline__ float bw_exp_nonpos(float x)
     return __builtin_ldexpf(r, (int)e);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 bw_exp_nonpos2(f32x2 x)
+{
+    const f32x2 c = {0x1.715476p+0f, 0x1.715476p+0f}, cc = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+    const f32x2 ph = x * c;
+    f32x2 pl = __builtin_elementwise_fma(x, c, -ph);
+    pl = __builtin_elementwise_fma(x, cc, pl);
+    const f32x2 e = {__builtin_rintf(ph.x), __builtin_rintf(ph.y)};
+    const f32x2 a = (ph - e) + pl;
+    f32x2 r;
+    r.x = __builtin_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)e.x);
+    r.y = __builtin_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)e.y);
+    return r;
+}
+
 // ---- cross-lane helpers -------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov(float old, float v)
@@ -290,15 +306,23 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             float dxs[BGRP], dys[BGRP], Gs[BGRP], alphas[BGRP];
             bool hits[BGRP];
             bool any_lane_hit = false;
+            // pairs of entries on float2: the arithmetic maps onto packed fp32 instructions (two IEEE operations per
+            // lane per issue slot); per-component rounding is unchanged, so power / alpha / hit equal the forward's
 #pragma unroll
-            for (int k = 0; k < BGRP; k++) {
-                const float dx = ex[k] - pixf_x, dy = ey[k] - pixf_y;
-                const float power = -0.5f * (eA[k] * dx * dx + eC[k] * dy * dy) - eB[k] * dx * dy;
-                const float G = bw_exp_nonpos(power);
-                const float alpha = fminf(0.99f, eo[k] * G);
-                dxs[k] = dx; dys[k] = dy; Gs[k] = G; alphas[k] = alpha;
-                hits[k] = (ef[k] < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                any_lane_hit = any_lane_hit || hits[k];
+            for (int k = 0; k < BGRP; k += 2) {
+                const f32x2 X = {ex[k], ex[k + 1]}, Y = {ey[k], ey[k + 1]}, A2 = {eA[k], eA[k + 1]};
+                const f32x2 B2 = {eB[k], eB[k + 1]}, C2 = {eC[k], eC[k + 1]}, O2 = {eo[k], eo[k + 1]};
+                const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
+                const f32x2 power = -0.5f * (A2 * dx * dx + C2 * dy * dy) - B2 * dx * dy;
+                const f32x2 G = bw_exp_nonpos2(power);
+                const f32x2 al = O2 * G;
+                dxs[k] = dx.x; dxs[k + 1] = dx.y; dys[k] = dy.x; dys[k + 1] = dy.y;
+                Gs[k] = G.x; Gs[k + 1] = G.y;
+                alphas[k] = fminf(0.99f, al.x);
+                alphas[k + 1] = fminf(0.99f, al.y);
+                hits[k] = (ef[k] < last_contributor) && !(power.x > 0.0f) && !(alphas[k] < 1.0f / 255.0f);
+                hits[k + 1] = (ef[k + 1] < last_contributor) && !(power.y > 0.0f) && !(alphas[k + 1] < 1.0f / 255.0f);
+                any_lane_hit = any_lane_hit || hits[k] || hits[k + 1];
             }
             if (!__any(any_lane_hit)) continue;
 
@@ -329,25 +353,31 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 last_d = hit ? d : last_d;
                 last_alpha = hit ? alpha : last_alpha;
             }
-            // Phase 2: the 4 x 9 partial derivatives of this lane's pixel
+            // Phase 2: the 4 x 9 partial derivatives of this lane's pixel, again on entry pairs
             float v[32], xo[BGRP];
 #pragma unroll
-            for (int k = 0; k < BGRP; k++) {
-                const float dx = dxs[k], dy = dys[k];
-                const float dL_dG = eo[k] * dLa[k];
-                const float gdx = Gh[k] * dx, gdy = Gh[k] * dy;
-                const float dG_ddelx = -__builtin_fmaf(gdx, eA[k], gdy * eB[k]);
-                const float dG_ddely = -__builtin_fmaf(gdy, eC[k], gdx * eB[k]);
-                const float h = -0.5f * dL_dG;
-                v[8 * k + 0] = dL_dG * dG_ddelx * ddelx_dx;
-                v[8 * k + 1] = dL_dG * dG_ddely * ddely_dy;
-                v[8 * k + 2] = h * gdx * dx;
-                v[8 * k + 3] = h * gdx * dy;
-                v[8 * k + 4] = h * gdy * dy;
-                v[8 * k + 5] = dch[k] * dpx0;
-                v[8 * k + 6] = dch[k] * dpx1;
-                v[8 * k + 7] = dch[k] * dpx2;
-                xo[k] = Gh[k] * dLa[k];
+            for (int k = 0; k < BGRP; k += 2) {
+                const f32x2 dx = {dxs[k], dxs[k + 1]}, dy = {dys[k], dys[k + 1]};
+                const f32x2 O2 = {eo[k], eo[k + 1]}, A2 = {eA[k], eA[k + 1]}, B2 = {eB[k], eB[k + 1]}, C2 = {eC[k], eC[k + 1]};
+                const f32x2 dLa2 = {dLa[k], dLa[k + 1]}, Gh2 = {Gh[k], Gh[k + 1]}, dch2 = {dch[k], dch[k + 1]};
+                const f32x2 dL_dG = O2 * dLa2;
+                const f32x2 gdx = Gh2 * dx, gdy = Gh2 * dy;
+                const f32x2 dG_ddelx = -__builtin_elementwise_fma(gdx, A2, gdy * B2);
+                const f32x2 dG_ddely = -__builtin_elementwise_fma(gdy, C2, gdx * B2);
+                const f32x2 h = -0.5f * dL_dG;
+                const f32x2 m0 = dL_dG * dG_ddelx * ddelx_dx, m1 = dL_dG * dG_ddely * ddely_dy;
+                const f32x2 c0v = h * gdx * dx, c1v = h * gdx * dy, c3v = h * gdy * dy;
+                const f32x2 k0 = dch2 * dpx0, k1 = dch2 * dpx1, k2 = dch2 * dpx2;
+                const f32x2 op = Gh2 * dLa2;
+                v[8 * k + 0] = m0.x; v[8 * k + 8] = m0.y;
+                v[8 * k + 1] = m1.x; v[8 * k + 9] = m1.y;
+                v[8 * k + 2] = c0v.x; v[8 * k + 10] = c0v.y;
+                v[8 * k + 3] = c1v.x; v[8 * k + 11] = c1v.y;
+                v[8 * k + 4] = c3v.x; v[8 * k + 12] = c3v.y;
+                v[8 * k + 5] = k0.x; v[8 * k + 13] = k0.y;
+                v[8 * k + 6] = k1.x; v[8 * k + 14] = k1.y;
+                v[8 * k + 7] = k2.x; v[8 * k + 15] = k2.y;
+                xo[k] = op.x; xo[k + 1] = op.y;
             }
             // reduce over the 64 pixels, then one atomic instruction for the whole group
             const float w = reduce32_transposed(v, lane);
