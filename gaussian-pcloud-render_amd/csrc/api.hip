@@ -342,7 +342,6 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     case GSR_Q_FINAL_T: src = iv.final_T; bytes = (size_t)N * 4; break;
     case GSR_Q_N_CONTRIB: src = iv.n_contrib; bytes = (size_t)N * 4; break;
     case GSR_Q_TILE_NEED: src = iv.tile_need; bytes = (size_t)T * 4; break;
-    case GSR_Q_TILE_CLOCK: src = iv.tile_clock; bytes = (size_t)T * 32; break;
     default: return fail(GSR_ERR_INVALID, "[gsr] query: unknown item %d", what);
     }
     if (dst_bytes < bytes) return fail(GSR_ERR_CAPACITY, "[gsr] query %d: destination too small", what);

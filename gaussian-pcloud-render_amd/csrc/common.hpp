@@ -70,7 +70,6 @@ struct ImageView {
     uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
     uint32_t* tile_order_bwd; // [T] tiles by descending consumed entries (backward render launch order)
     uint32_t* tile_need;  // [T] entries walked by the forward render (instrumentation for the bytes model)
-    uint64_t* tile_clock; // [T,4] wall_clock64 (100 MHz) at start/end of the tile's forward and backward workgroup (debug)
     size_t bytes;
 };
 
@@ -133,7 +132,6 @@ inline ImageView image_view(void* base, int W, int H)
     carve(cur, v.tile_order, T ? T : 1);
     carve(cur, v.tile_order_bwd, T ? T : 1);
     carve(cur, v.tile_need, T ? T : 1);
-    carve(cur, v.tile_clock, 4 * (T ? T : 1));
     v.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return v;
 }

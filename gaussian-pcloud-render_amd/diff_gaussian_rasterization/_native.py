@@ -35,7 +35,7 @@ SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forwar
            "gsr_version", "gsr_selftest", "gsr_forward_recolor")
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
-         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, TILE_CLOCK=13)
+         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12)
 
 
 def _load():
@@ -248,7 +248,6 @@ _QSPEC = {
     "POINT_LIST_KEYS": (torch.int64, lambda P, R, T, N: (R,)), "RANGES": (torch.int32, lambda P, R, T, N: (T, 2)),
     "FINAL_T": (torch.float32, lambda P, R, T, N: (N,)), "N_CONTRIB": (torch.int32, lambda P, R, T, N: (N,)),
     "CLAMPED": (torch.uint8, lambda P, R, T, N: (P, 3)), "TILE_NEED": (torch.int32, lambda P, R, T, N: (T,)),
-    "TILE_CLOCK": (torch.int64, lambda P, R, T, N: (T, 4)),
 }
 
 

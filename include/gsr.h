@@ -128,7 +128,6 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 #define GSR_Q_FINAL_T 9        /* float  [H*W]                                                              */
 #define GSR_Q_N_CONTRIB 10     /* uint32 [H*W]                                                              */
 #define GSR_Q_TILE_NEED 12     /* uint32 [T]   list entries the tile's render actually walked (roofline model)    */
-#define GSR_Q_TILE_CLOCK 13    /* uint64 [T,4] 100 MHz wall clock at start/end of each tile's fwd / bwd workgroup     */
 #define GSR_Q_CLAMPED 11       /* uint8  [P,3]                                                              */
 int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, const void* image,
               int64_t num_rendered, void* dst, size_t dst_bytes, gsr_stream_t stream);
