@@ -8,9 +8,10 @@
 //   8-B pairs).  Stability of both steps gives exactly: tile, then depth bits, then Gaussian id.
 //
 // One pass = three launches: per-workgroup digit histogram, per-digit row scan, stable scatter.
-// The scatter ranks keys with wave64 ballots (8 ballots = one 8-bit digit match), reorders the
-// workgroup's 4096 pairs in LDS, then writes digit runs with consecutive lanes on consecutive
-// addresses.
+// The scatter ranks keys with wave64 ballots (one ballot per digit bit), reorders the workgroup's 4096
+// pairs in LDS, then writes digit runs with consecutive lanes on consecutive addresses.  The key bits
+// are split evenly over the passes (13 bits -> 7 + 6, not 8 + 5): narrower digits mean fewer ballots
+// and longer, better coalesced runs per workgroup.
 #include "common.hpp"
 
 namespace gsr {
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 }
 
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
+template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index
                                                               uint32_t* __restrict__ keys_out,
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
         const uint32_t d = (k[j] >> shift) & mask;
         uint64_t peers = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < RADIX_BITS; b++) {
+        for (int b = 0; b < BITS; b++) {
             const uint64_t bal = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
@@ -185,19 +187,30 @@ int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32
     if (n > 0) {
         const int nblk = (int)div_up(n, RS_TILE);
         bool first = true;
-        for (int shift = 0; shift < end_bit; shift += RADIX_BITS) {
-            const int bits = end_bit - shift < RADIX_BITS ? end_bit - shift : RADIX_BITS;
+        const int npass = (end_bit + RADIX_BITS - 1) / RADIX_BITS;
+        int shift = 0;
+        for (int pass = 0; pass < npass; pass++) {
+            const int bits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);   // even split, wider digits first
             const uint32_t mask = (1u << bits) - 1u;
             hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_THREADS), 0, L.stream, key[cur], n, shift, mask, hist, nblk);
             if (int e = check_launch(L, "radix_hist")) return e;
             hipLaunchKernelGGL(k_radix_rowscan, dim3(RADIX), dim3(256), 0, L.stream, hist, totals, nblk);
             if (int e = check_launch(L, "radix_rowscan")) return e;
-            hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(RS_THREADS), 0, L.stream, key[cur],
-                               (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)val[cur], key[cur ^ 1],
-                               val[cur ^ 1], n, shift, mask, hist, totals, nblk);
+            const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)val[cur];
+#define GSR_SCATTER(B)                                                                                                   \
+    case B:                                                                                                              \
+        hipLaunchKernelGGL(k_radix_scatter<B>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, key[cur], vin, key[cur ^ 1],  \
+                           val[cur ^ 1], n, shift, mask, hist, totals, nblk);                                            \
+        break;
+            switch (bits) {
+                GSR_SCATTER(1) GSR_SCATTER(2) GSR_SCATTER(3) GSR_SCATTER(4) GSR_SCATTER(5) GSR_SCATTER(6) GSR_SCATTER(7)
+                GSR_SCATTER(8)
+            }
+#undef GSR_SCATTER
             if (int e = check_launch(L, "radix_scatter")) return e;
             cur ^= 1;
             first = false;
+            shift += bits;
         }
     }
     *result_buffer = cur;
