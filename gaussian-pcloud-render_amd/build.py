@@ -22,7 +22,7 @@ UNITS = ["api", "preprocess", "sort", "binning", "render_fwd", "render_bwd", "pr
 # -ffp-contract=off : one rounding per written operation (integer outputs reproducible, DESIGN.md "Numerics")
 # -munsafe-fp-atomics: float atomicAdd -> global_atomic_add_f32 / ds_add_f32 instead of a CAS loop
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", *os.environ.get("GSR_EXTRA_FLAGS", "").split()]
 
 
 def _deps_mtime():

@@ -24,7 +24,6 @@
 
 namespace gsr {
 
-constexpr int GRP = 4;  // entries evaluated per inner-loop trip
 
 struct RenderArgs {
     const uint2* ranges;
@@ -53,7 +52,11 @@ __device__ __forceinline__ void prefetch4(uint32_t& dst, const void* p)
 {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
-__device__ __forceinline__ void retire_prefetch(f32x4& a, f32x4& b, f32x4& c, uint32_t& d)
+__device__ __forceinline__ void prefetch4f(float& dst, const void* p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void retire_prefetch(f32x4& a, f32x4& b, float& c, uint32_t& d)
 {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
@@ -91,9 +94,44 @@ __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x)
     return r;
 }
 
-__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+// Broadcast of the surviving entries to the 64 pixels goes through LDS: the lanes whose entry survived the footprint
+// test write their records, compacted and interleaved in PAIRS (x0 x1 y0 y1 | A0 A1 B0 B1 | C0 C1 o0 o1 |
+// r0 g0 r1 g1 | b0 b1), and the wave reads one pair back with five same-address ds_read (every lane gets every
+// value; operands arrive as the register pairs the packed fp32 instructions want).  The obvious alternative, nine
+// v_readlane per entry, costs about as many VALU issue cycles as the whole alpha evaluation (measured: one
+// v_readlane ~ 2-3 plain VALU ops, scripts/probe/readlane_probe.hip), and this kernel is VALU-issue bound; scalar
+// loads (s_load through the scalar cache) have the right cost but ~1 us latency, which the serial walk of the
+// longest lists cannot hide.  A wave owns its 2.5 KB of LDS: no barrier anywhere (DS operations of one wave execute
+// in order).
+constexpr int PAIR_WORDS = 20;  // 18 used, padded so each pair starts on a 16-B boundary
+
+// lowest one or two set bits of the survivor mask (the second defaults to the first when only one is left)
+__device__ __forceinline__ void take_pair(uint64_t& mask, int& j0, int& j1)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+    j0 = (int)__builtin_ctzll(mask);
+    mask &= mask - 1;
+    const bool two = mask != 0;
+    j1 = two ? (int)__builtin_ctzll(mask) : j0;
+    mask = two ? (mask & (mask - 1)) : 0;
+}
+
+struct PairRec {
+    f32x4 xy;   // x0 x1 y0 y1
+    f32x4 ab;   // A0 A1 B0 B1
+    f32x4 co;   // C0 C1 o0 o1
+    f32x4 rg;   // r0 g0 r1 g1
+    f32x2 b;    // b0 b1
+};
+__device__ __forceinline__ PairRec read_pair(const float* lds, int pair)
+{
+    const float* p = lds + pair * PAIR_WORDS;
+    PairRec r;
+    r.xy = *(const f32x4*)(p + 0);
+    r.ab = *(const f32x4*)(p + 4);
+    r.co = *(const f32x4*)(p + 8);
+    r.rg = *(const f32x4*)(p + 12);
+    r.b = *(const f32x2*)(p + 16);
+    return r;
 }
 
 __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
@@ -113,6 +151,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     const float pixf_x = (float)px, pixf_y = (float)py;
     const float x0f = (float)x0, y0f = (float)y0;
 
+    __shared__ __attribute__((aligned(16))) float stage[32 * PAIR_WORDS];
+
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
 
@@ -129,27 +169,27 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         // software pipeline: records of round r+1 and ids of round r+2 are in flight while round r is evaluated.
         // Lanes past the end of the list read entry total-1 again (always a valid address) and are masked by `valid`.
         const int last = total - 1;
-        f32x4 c0, c1, c2, n0, n1, n2;
-        uint32_t id_nxt, id_nn;
+        f32x4 c0, c1, n0, n1;
+        float c2b, n2b;  // blue
+        uint32_t id_cur, id_nxt, id_nn;
         {
             // prologue: round 0's records and round 1's ids, through the same asm path so that no compiler-tracked
             // load is pending when the loop is entered
-            uint32_t id0;
-            prefetch4(id0, plist + ((int)lane < total ? (int)lane : last));
+            prefetch4(id_cur, plist + ((int)lane < total ? (int)lane : last));
             prefetch4(id_nxt, plist + (64 + (int)lane < total ? 64 + (int)lane : last));
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(id0), "+v"(id_nxt)::"memory");
-            const Splat* sp = a.splat + id0;
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
+            const Splat* sp = a.splat + id_cur;
             prefetch16(c0, &sp->q0);
             prefetch16(c1, &sp->q1);
-            prefetch16(c2, &sp->q2);
-            retire_prefetch(c0, c1, c2, id_nxt);
+            prefetch4f(c2b, &sp->q2);
+            retire_prefetch(c0, c1, c2b, id_nxt);
         }
         for (int base = 0; base < total; base += 64) {
             {
                 const Splat* sp = a.splat + id_nxt;
                 prefetch16(n0, &sp->q0);
                 prefetch16(n1, &sp->q1);
-                prefetch16(n2, &sp->q2);
+                prefetch4f(n2b, &sp->q2);
                 const int i2 = base + 128 + (int)lane;
                 prefetch4(id_nn, plist + (i2 < total ? i2 : last));
             }
@@ -159,79 +199,88 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
             const bool touch = valid && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
             uint64_t mask = __ballot(touch);
 
-            while (mask != 0 && !all_done) {
-                float ex[GRP], ey[GRP], eA[GRP], eB[GRP], eC[GRP], eo[GRP], er[GRP], eg[GRP], eb[GRP];
-                uint32_t eidx[GRP];
-#pragma unroll
-                for (int k = 0; k < GRP; k++) {
-                    const bool have = mask != 0;
-                    const int j = have ? (int)__builtin_ctzll(mask) : 0;
-                    mask = have ? (mask & (mask - 1)) : 0;
-                    ex[k] = lane_bcast(c0.x, j); ey[k] = lane_bcast(c0.y, j);
-                    eA[k] = lane_bcast(c0.z, j); eB[k] = lane_bcast(c0.w, j);
-                    eC[k] = lane_bcast(c1.x, j);
-                    const float o = lane_bcast(c1.y, j);
-                    eo[k] = have ? o : 0.f;  // opacity 0 -> alpha 0 -> the 1/255 test drops the slot
-                    er[k] = lane_bcast(c1.z, j); eg[k] = lane_bcast(c1.w, j); eb[k] = lane_bcast(c2.x, j);
-                    eidx[k] = (uint32_t)(base + j + 1);  // 1-based position in the tile list
+            if (mask != 0) {
+                // stage the survivors: lane -> compacted slot -> (pair, half)
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t nsurv = (uint32_t)__popcll(mask);
+                if (touch) {
+                    float* p = stage + (slot >> 1) * PAIR_WORDS + (slot & 1u);
+                    p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
+                    float* pc = stage + (slot >> 1) * PAIR_WORDS + 12 + 2 * (slot & 1u);
+                    pc[0] = c1.z; pc[1] = c1.w;
+                    p[16] = c2b;
+                    if (slot + 1 == nsurv && (slot & 1u) == 0) {
+                        // odd count: the missing partner is a copy with opacity 0 -> alpha 0 -> the 1/255 test drops it
+                        p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
+                        pc[2] = c1.z; pc[3] = c1.w;
+                        p[17] = c2b;
+                    }
                 }
-                // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  Entries are taken in
-                // pairs so the arithmetic maps onto packed fp32 instructions (this kernel is VALU-issue bound).
-                float alpha[GRP], ae[GRP];
-                bool cnt[GRP];
-#pragma unroll
-                for (int k = 0; k < GRP; k += 2) {
-                    const f32x2 X = {ex[k], ex[k + 1]}, Y = {ey[k], ey[k + 1]}, A2 = {eA[k], eA[k + 1]};
-                    const f32x2 B2 = {eB[k], eB[k + 1]}, C2 = {eC[k], eC[k + 1]}, O2 = {eo[k], eo[k + 1]};
+                // pair p+1 is read from LDS while pair p is evaluated
+                int pair = 0;
+                PairRec r = read_pair(stage, 0), m = r;
+                for (;;) {
+                    int j0, j1;
+                    take_pair(mask, j0, j1);
+                    const bool more = mask != 0;
+                    if (more) m = read_pair(stage, pair + 1);
+                    // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
+                    // share packed fp32 instructions (v_pk_*_f32).
+                    const uint32_t eidx0 = (uint32_t)(base + j0 + 1), eidx1 = (uint32_t)(base + j1 + 1);  // 1-based list position
+                    const f32x2 X = {r.xy.x, r.xy.y}, Y = {r.xy.z, r.xy.w}, A2 = {r.ab.x, r.ab.y}, B2 = {r.ab.z, r.ab.w};
+                    const f32x2 C2p = {r.co.x, r.co.y}, O2 = {r.co.z, r.co.w};
                     const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
-                    const f32x2 power = -0.5f * (A2 * dx * dx + C2 * dy * dy) - B2 * dx * dy;
+                    const f32x2 power = -0.5f * (A2 * dx * dx + C2p * dy * dy) - B2 * dx * dy;
                     const f32x2 al = O2 * exp_nonpos2(power);
-                    alpha[k] = fminf(0.99f, al.x);
-                    alpha[k + 1] = fminf(0.99f, al.y);
-                    cnt[k] = !done && !(power.x > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
-                    cnt[k + 1] = !done && !(power.y > 0.0f) && !(alpha[k + 1] < 1.0f / 255.0f);
-                    ae[k] = cnt[k] ? alpha[k] : 0.f;
-                    ae[k + 1] = cnt[k + 1] ? alpha[k + 1] : 0.f;
-                }
-                // Optimistic pass: assume no pixel of this wave terminates inside the group.  T then only needs the
-                // products T*(1-ae) (ae = 0 multiplies by exactly 1), and because T never increases and every live
-                // pixel has T >= 1e-4, "some entry of the group would have stopped a pixel" is just T_after < 1e-4.
-                // A pixel stops once, so the exact serial fallback runs for at most 64 groups per wave per tile.
-                float Tk[GRP + 1];
-                Tk[0] = T;
-#pragma unroll
-                for (int k = 0; k < GRP; k++) Tk[k + 1] = Tk[k] * (1 - ae[k]);
-                if (!__any(Tk[GRP] < 0.0001f)) {
-#pragma unroll
-                    for (int k = 0; k < GRP; k++) {
+                    const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+                    const bool cnt0 = !done && !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
+                    const bool cnt1 = !done && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
+                    const float ae0 = cnt0 ? alpha0 : 0.f, ae1 = cnt1 ? alpha1 : 0.f;
+                    // Optimistic pass: assume no pixel of this wave terminates inside the pair.  T then only needs the
+                    // products T*(1-ae) (ae = 0 multiplies by exactly 1), and because T never increases and every live
+                    // pixel has T >= 1e-4, "an entry of the pair would have stopped a pixel" is just T_after < 1e-4.
+                    // A pixel stops once, so the exact serial fallback runs for at most 64 pairs per wave per tile.
+                    const float T1 = T * (1 - ae0), T2 = T1 * (1 - ae1);
+                    if (!__any(T2 < 0.0001f)) {
                         // ae = 0 adds a zero, which leaves C unchanged bit-for-bit (C is never -0)
-                        const f32x2 rg = {er[k], eg[k]};
-                        C01 += rg * ae[k] * Tk[k];
-                        C2 += eb[k] * ae[k] * Tk[k];
-                        last_contributor = cnt[k] ? eidx[k] : last_contributor;
-                    }
-                    T = Tk[GRP];
-                } else {
+                        const f32x2 rg0 = {r.rg.x, r.rg.y}, rg1 = {r.rg.z, r.rg.w};
+                        C01 += rg0 * ae0 * T;
+                        C2 += r.b.x * ae0 * T;
+                        C01 += rg1 * ae1 * T1;
+                        C2 += r.b.y * ae1 * T1;
+                        last_contributor = cnt0 ? eidx0 : last_contributor;
+                        last_contributor = cnt1 ? eidx1 : last_contributor;
+                        T = T2;
+                    } else {
+                        const float al_[2] = {alpha0, alpha1};
+                        const bool cn_[2] = {cnt0, cnt1};
+                        const float cr_[2] = {r.rg.x, r.rg.z}, cg_[2] = {r.rg.y, r.rg.w}, cb_[2] = {r.b.x, r.b.y};
+                        const uint32_t ei_[2] = {eidx0, eidx1};
 #pragma unroll
-                    for (int k = 0; k < GRP; k++) {
-                        const float test_T = T * (1 - alpha[k]);
-                        const bool hit = !done && cnt[k];
-                        const bool stop = hit && (test_T < 0.0001f);
-                        const bool blend = hit && !stop;
-                        C01.x += blend ? er[k] * alpha[k] * T : 0.f;
-                        C01.y += blend ? eg[k] * alpha[k] * T : 0.f;
-                        C2 += blend ? eb[k] * alpha[k] * T : 0.f;
-                        T = blend ? test_T : T;
-                        last_contributor = blend ? eidx[k] : last_contributor;
-                        stop_at = stop ? eidx[k] : stop_at;
-                        done = done || stop;
+                        for (int k = 0; k < 2; k++) {
+                            const float test_T = T * (1 - al_[k]);
+                            const bool hit = !done && cn_[k];
+                            const bool stop = hit && (test_T < 0.0001f);
+                            const bool blend = hit && !stop;
+                            C01.x += blend ? cr_[k] * al_[k] * T : 0.f;
+                            C01.y += blend ? cg_[k] * al_[k] * T : 0.f;
+                            C2 += blend ? cb_[k] * al_[k] * T : 0.f;
+                            T = blend ? test_T : T;
+                            last_contributor = blend ? ei_[k] : last_contributor;
+                            stop_at = stop ? ei_[k] : stop_at;
+                            done = done || stop;
+                        }
+                        all_done = __all(done);
                     }
-                    all_done = __all(done);
+                    if (!more || all_done) break;
+                    r = m;
+                    pair++;
                 }
             }
-            retire_prefetch(n0, n1, n2, id_nn);
+            retire_prefetch(n0, n1, n2b, id_nn);
             if (all_done) break;
-            c0 = n0; c1 = n1; c2 = n2;
+            c0 = n0; c1 = n1; c2b = n2b;
+            id_cur = id_nxt;
             id_nxt = id_nn;
         }
     }
