@@ -37,11 +37,16 @@ __device__ __forceinline__ void bw_prefetch4(uint32_t& dst, const void* p)
 {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
-
-__device__ __forceinline__ float bw_bcast(float v, int src_lane)
+__device__ __forceinline__ void bw_prefetch4f(float& dst, const void* p)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+
+// LDS staging of the surviving entries (see render_fwd.hip for why not v_readlane): compacted, four entries per
+// group, component-major inside the group: x0..x3 | y0..y3 | A | B | C | opacity | r | g | b | id  (10 x 16 B), so one
+// same-address ds_read_b128 per component hands every lane the four entries' values, pairs adjacent for the
+// packed fp32 instructions.
+constexpr int QUAD_WORDS = 40;
 
 // core of ocml expf without its range clamps; bit-identical to expf on [-103, 0] (see render_fwd.hip)
 __device__ __forceinline__ float bw_exp_nonpos(float x)
@@ -254,13 +259,20 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         tgt_stride = 4;
     }
 
+    // the staging area starts as zeros, so slots of a partly filled last group always hold finite values (their
+    // opacity is set to 0 every round, which is what keeps them from ever hitting)
+    __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
+#pragma unroll
+    for (int i = 0; i < 16 * QUAD_WORDS / 64; i++) stage[i * 64 + lane] = 0.f;
+
     float s_rec = 0.f;                        // accum_rec . dL_dpixel
     float last_alpha = 0.f, last_d = 0.f;     // last alpha, last_color . dL_dpixel
 
     const uint32_t* plist = a.point_list + range.x;
     // Round r covers front indices hi-64 .. hi-1 (hi = total - 64 r), lane i <-> f = hi-1-i, so the lowest set bit of
     // the ballot is the entry nearest the back.  Lanes whose f would be negative re-read entry 0 and are masked.
-    f32x4 c0, c1, c2, n0, n1, n2;
+    f32x4 c0, c1, n0, n1;
+    float c2b, n2b;  // blue
     uint32_t id_cur, id_nxt, id_nn;
     {
         const int f0 = total - 1 - (int)lane, f1 = total - 65 - (int)lane;
@@ -270,15 +282,15 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         const Splat* sp = a.splat + id_cur;
         bw_prefetch16(c0, &sp->q0);
         bw_prefetch16(c1, &sp->q1);
-        bw_prefetch16(c2, &sp->q2);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2)::"memory");
+        bw_prefetch4f(c2b, &sp->q2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2b)::"memory");
     }
     for (int hi = total; hi > 0; hi -= 64) {
         {
             const Splat* sp = a.splat + id_nxt;
             bw_prefetch16(n0, &sp->q0);
             bw_prefetch16(n1, &sp->q1);
-            bw_prefetch16(n2, &sp->q2);
+            bw_prefetch4f(n2b, &sp->q2);
             const int f2 = hi - 129 - (int)lane;
             bw_prefetch4(id_nn, plist + (f2 >= 0 ? f2 : 0));
         }
@@ -286,21 +298,35 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         const bool touch = f_lane >= 0 && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
         uint64_t mask = __ballot(touch);
 
+        if (mask != 0) {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t nsurv = (uint32_t)__popcll(mask);
+            if (lane < 4) stage[((nsurv - 1) >> 2) * QUAD_WORDS + 20 + lane] = 0.f;  // opacity row of the last group
+            if (touch) {
+                float* p = stage + (slot >> 2) * QUAD_WORDS + (slot & 3u);
+                p[0] = c0.x; p[4] = c0.y; p[8] = c0.z; p[12] = c0.w; p[16] = c1.x; p[20] = c1.y;
+                p[24] = c1.z; p[28] = c1.w; p[32] = c2b; p[36] = __builtin_bit_cast(float, id_cur);
+            }
+        }
+        int quad = 0;
         while (mask != 0) {
             float ex[BGRP], ey[BGRP], eA[BGRP], eB[BGRP], eC[BGRP], eo[BGRP], er[BGRP], eg[BGRP], eb[BGRP];
-            uint32_t ef[BGRP], eid[BGRP];
+            uint32_t ef[BGRP];
+            {
+                const f32x4* p = (const f32x4*)(stage + quad * QUAD_WORDS);
+                const f32x4 X = p[0], Y = p[1], A4 = p[2], B4 = p[3], C4 = p[4], O4 = p[5], R4 = p[6], G4 = p[7], Bl = p[8];
+#pragma unroll
+                for (int k = 0; k < BGRP; k++) {
+                    ex[k] = X[k]; ey[k] = Y[k]; eA[k] = A4[k]; eB[k] = B4[k]; eC[k] = C4[k]; eo[k] = O4[k];
+                    er[k] = R4[k]; eg[k] = G4[k]; eb[k] = Bl[k];
+                }
+                quad++;
+            }
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
                 const bool have = mask != 0;
                 const int j = have ? (int)__builtin_ctzll(mask) : 0;
                 mask = have ? (mask & (mask - 1)) : 0;
-                ex[k] = bw_bcast(c0.x, j); ey[k] = bw_bcast(c0.y, j);
-                eA[k] = bw_bcast(c0.z, j); eB[k] = bw_bcast(c0.w, j);
-                eC[k] = bw_bcast(c1.x, j);
-                const float o = bw_bcast(c1.y, j);
-                eo[k] = have ? o : 0.f;  // opacity 0 -> alpha 0 -> never hits
-                er[k] = bw_bcast(c1.z, j); eg[k] = bw_bcast(c1.w, j); eb[k] = bw_bcast(c2.x, j);
-                eid[k] = (uint32_t)__builtin_amdgcn_readlane((int)id_cur, j);
                 ef[k] = (uint32_t)(hi - 1 - j);  // 0-based position of the entry in the tile list
             }
             float dxs[BGRP], dys[BGRP], Gs[BGRP], alphas[BGRP];
@@ -383,14 +409,12 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const float w = reduce32_transposed(v, lane);
             const float z = reduce4_rows(xo[0], xo[1], xo[2], xo[3]);
             const float val = (lane & 1u) ? z : w;
-            uint32_t id = eid[0];
-            id = tgt_k == 1 ? eid[1] : id;
-            id = tgt_k == 2 ? eid[2] : id;
-            id = tgt_k == 3 ? eid[3] : id;
+            // this lane's entry id, straight from the id row of the group
+            const uint32_t id = __builtin_bit_cast(uint32_t, stage[(quad - 1) * QUAD_WORDS + 36 + tgt_k]);
             if (tgt_on && val != 0.f) atomicAdd(reinterpret_cast<float*>(tgt_base + (size_t)id * tgt_stride), val);
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(id_nn)::"memory");
-        c0 = n0; c1 = n1; c2 = n2;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2b), "+v"(id_nn)::"memory");
+        c0 = n0; c1 = n1; c2b = n2b;
         id_cur = id_nxt;
         id_nxt = id_nn;
     }
