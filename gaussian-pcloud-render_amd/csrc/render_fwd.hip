@@ -216,14 +216,9 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         p[17] = c2b;
                     }
                 }
-                // pair p+1 is read from LDS while pair p is evaluated
-                int pair = 0;
-                PairRec r = read_pair(stage, 0), m = r;
-                for (;;) {
-                    int j0, j1;
-                    take_pair(mask, j0, j1);
-                    const bool more = mask != 0;
-                    if (more) m = read_pair(stage, pair + 1);
+                // Pair p+1 is read from LDS while pair p is evaluated.  The loop body is written out twice with the two
+                // register sets swapped, so no register moves are needed to rotate them.
+                auto eval_pair = [&](const PairRec& r, int j0, int j1) {
                     // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
                     // share packed fp32 instructions (v_pk_*_f32).
                     const uint32_t eidx0 = (uint32_t)(base + j0 + 1), eidx1 = (uint32_t)(base + j1 + 1);  // 1-based list position
@@ -272,9 +267,22 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         }
                         all_done = __all(done);
                     }
+                };
+                int pair = 0;
+                PairRec ra = read_pair(stage, 0), rb;  // rb is always read from LDS before it is evaluated
+                for (;;) {
+                    int j0, j1;
+                    take_pair(mask, j0, j1);
+                    bool more = mask != 0;
+                    if (more) rb = read_pair(stage, pair + 1);
+                    eval_pair(ra, j0, j1);
                     if (!more || all_done) break;
-                    r = m;
-                    pair++;
+                    take_pair(mask, j0, j1);
+                    more = mask != 0;
+                    if (more) ra = read_pair(stage, pair + 2);
+                    eval_pair(rb, j0, j1);
+                    if (!more || all_done) break;
+                    pair += 2;
                 }
             }
             retire_prefetch(n0, n1, n2b, id_nn);
