@@ -1,0 +1,93 @@
+"""Randomised parity sweep: seeded random scene configurations (image size incl. odd / sub-tile sizes, Gaussian count,
+footprint scale, SH degree / precomputed colours, precomputed covariance, scale modifier, background, camera pose on
+the reference's circle path) rendered by the HIP library and by the reference build (oracle/_ref, the reference's own
+kernels compiled for gfx950): integer outputs and forward floats must be bit-identical, gradients within tolerance.
+Each case is tiny, so the sweep also hits the degenerate ends (P = 1, 1x1 tile grids, lists shorter than a round,
+lists of several rounds, everything culled)."""
+import numpy as np
+import pytest
+
+import util
+from util import run_product
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 128
+
+
+def _ref():
+    from oracle.oracle import Reference
+    if not Reference.available("strict"):
+        pytest.skip("oracle/_ref not built")
+    return Reference("strict")
+
+
+def _case(i):
+    from pcrender import camera, synth
+    rng = np.random.default_rng(1000 + i)
+    W = int(rng.choice([1, 7, 16, 17, 31, 33, 64, 97, 130, 200]))
+    H = int(rng.choice([1, 5, 16, 23, 32, 48, 65, 111]))
+    P = int(rng.choice([1, 2, 63, 64, 65, 300, 1500, 4000]))
+    D = int(rng.integers(0, 4))
+    rows = int(rng.choice([(D + 1) ** 2, 16, 13 if D <= 2 else 16]))
+    rows = max(rows, (D + 1) ** 2)
+    scale = float(rng.choice([0.004, 0.02, 0.05, 0.15, 0.4]))
+    spread = float(rng.choice([0.3, 1.0, 3.0]))
+    g = synth.random_scene(P, W, H, seed=2000 + i, sh_degree=D, sh_rows=rows, spread=spread, scale=scale,
+                           anisotropy=float(rng.choice([0.5, 1.0, 2.0])))
+    if rng.random() < 0.3:
+        g["rotations"] = (g["rotations"] * rng.uniform(0.5, 1.6, (P, 1))).astype(np.float32)   # kernels never normalise (Q3)
+    if rng.random() < 0.2:
+        g["opacities"][:] = 1.0
+    if rng.random() < 0.15:
+        g["means3D"][:, 2] -= 5.0                                                              # mostly behind the camera
+    mode = "colors" if rng.random() < 0.25 else "sh"
+    use_cov = bool(rng.random() < 0.25)
+    mod = float(rng.choice([1.0, 1.0, 0.6, 2.5]))
+    bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+    if rng.random() < 0.5:
+        view = util.identity_camera(W, H, float(rng.choice([30.0, 45.0, 60.0, 80.0])))
+    else:                                   # the reference caller's circle camera, looking at the origin from r = 3
+        view = camera.circle_views(n_imgs=12, fov_deg=45.0, width_px=W, height_px=H)[int(rng.integers(0, 12))]
+        g["means3D"][:, 2] -= 3.0
+    return util.scene_from(g, view, W, H, bg=bg, mode=mode, scale_modifier=mod, use_cov3d=use_cov), mode
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_case_matches_reference_build(i, gpu_device):
+    ref = _ref()
+    s, mode = _case(i)
+    dL = util.seeded_dL(s, seed=77 + i)
+    r, gr = ref.forward_backward(s, dL)
+    p, gp = run_product(s, gpu_device, dL_dpix=dL)
+    assert p["R"] == r["R"]
+    for k in ("radii", "tiles_touched", "vals", "keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(p[k], r[k], err_msg="case %d %s" % (i, k))
+    vis = r["radii"] > 0
+    for k in ("depths", "means2D", "conic_opacity") + (() if mode == "colors" else ("rgb",)):
+        assert p[k][vis].tobytes() == r[k][vis].tobytes(), "case %d %s" % (i, k)
+    assert p["final_T"].tobytes() == r["final_T"].tobytes()
+    assert p["out_color"].tobytes() == r["out_color"].tobytes()
+    oracle_grads = None
+    for k, a in gp.items():
+        b = gr[k]
+        if a.size == 0 and b.size == 0:
+            continue
+        assert a.shape == b.shape, "case %d %s" % (i, k)
+        assert np.isfinite(a).all(), "case %d %s" % (i, k)
+        scale = np.abs(b).max()
+        d_ref = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+        if d_ref <= 2e-4 * scale + 1e-30:
+            continue
+        # Both sides sum thousands of fp32 terms in different (for the reference: unspecified, atomic) orders, and the
+        # per-Gaussian chain conic -> cov3D -> scale / rotation can amplify that rounding noise by 10^3 on an
+        # ill-conditioned splat (run-to-run variation of BOTH sides at the 1e-4 level has been observed on such cases).
+        # When they disagree beyond the bar, the plain-C oracle, which accumulates in double, arbitrates: the library
+        # must be about as close to it as the reference build is (factor 4 for the noise of a single run).
+        if oracle_grads is None:
+            from oracle.oracle import Oracle
+            oracle_grads = Oracle().forward_backward(s, dL)[1]
+        o = oracle_grads[k].astype(np.float64)
+        d_lib, d_build = np.abs(a - o).max(), np.abs(b - o).max()
+        assert d_lib <= max(4 * d_build, 2e-4 * scale), "case %d %s: lib-oracle %.3g, ref-oracle %.3g, lib-ref %.3g, max|g| %.3g" % (
+            i, k, d_lib, d_build, d_ref, scale)
