@@ -185,18 +185,18 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
     if (R > 0) {
         {
             ProfScope ps("duplicate", L.stream);
-            if (int e = launch_duplicate(L, p->P, g, g.dval[0], gridx, b.key[0], b.val[0])) return e;
+            if (int e = launch_duplicate(L, p->P, g, g.dval[0], gridx, b.key[0], b.val[0], tile_keys16(T))) return e;
         }
         {
             ProfScope ps("tile_sort", L.stream);
             uint32_t* key[2] = {b.key[0], b.key[1]};
             uint32_t* val[2] = {b.val[0], b.val[1]};
-            if (int e = launch_radix_sort_pairs(L, R, key, val, false, tile_bits(T), b.hist, b.totals, &res)) return e;
+            if (int e = launch_radix_sort_pairs(L, R, key, val, false, tile_bits(T), b.hist, b.totals, &res, tile_keys16(T))) return e;
         }
     }
     {
         ProfScope ps("tile_ranges", L.stream);
-        if (int e = launch_tile_ranges(L, R, b.key[res], iv.ranges, T)) return e;
+        if (int e = launch_tile_ranges(L, R, b.key[res], iv.ranges, T, tile_keys16(T))) return e;
         if (int e = launch_tile_order(L, iv, T, false)) return e;
     }
     {
@@ -289,7 +289,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 // ---- inspection (tests / roofline report only) -------------------------------------------------------
 namespace {
 __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const uint8_t* __restrict__ clamped,
-                        const uint32_t* __restrict__ k, const uint32_t* __restrict__ v, void* __restrict__ dst)
+                        const uint32_t* __restrict__ k, int key16, const uint32_t* __restrict__ v, void* __restrict__ dst)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -302,7 +302,7 @@ __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const
         break;
     case GSR_Q_RGB: d[3 * i] = sp[i].q1.z; d[3 * i + 1] = sp[i].q1.w; d[3 * i + 2] = sp[i].q2.x; break;
     case GSR_Q_POINT_LIST_KEYS:
-        ((uint64_t*)dst)[i] = ((uint64_t)k[i] << 32) | (uint64_t)__float_as_uint(sp[v[i]].q2.y);
+        ((uint64_t*)dst)[i] = ((uint64_t)(key16 ? (uint32_t)((const uint16_t*)k)[i] : k[i]) << 32) | (uint64_t)__float_as_uint(sp[v[i]].q2.y);
         break;
     case GSR_Q_CLAMPED: {
         uint8_t* c = (uint8_t*)dst;
@@ -350,7 +350,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query copy failed");
     } else {
         hipLaunchKernelGGL(k_query, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, what, n, g.splat, g.clamped, b.key[res],
-                           b.val[res], dst);
+                           (int)tile_keys16(T), b.val[res], dst);
         if (hipGetLastError() != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query kernel failed");
     }
     return GSR_OK;

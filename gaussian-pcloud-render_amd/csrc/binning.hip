@@ -12,11 +12,12 @@
 
 namespace gsr {
 
+template <typename KeyT>
 __global__ __launch_bounds__(256) void k_duplicate(int P, const uint32_t* __restrict__ order,
                                                    const uint32_t* __restrict__ dup_offset,
                                                    const uint32_t* __restrict__ tiles_touched,
                                                    const uint2* __restrict__ rect, uint32_t gridx,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                   KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t s_off[4][64];
     __shared__ uint32_t s_id[4][64];
@@ -63,20 +64,25 @@ __global__ __launch_bounds__(256) void k_duplicate(int P, const uint32_t* __rest
         const uint32_t width = maxx - minx;
         const uint32_t t = p - s_off[w][lo];
         const uint32_t row = t / width, col = t - row * width;
-        keys[p] = (miny + row) * gridx + (minx + col);
+        keys[p] = (KeyT)((miny + row) * gridx + (minx + col));
         vals[p] = s_id[w][lo];
     }
 }
 
 int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
-                     uint32_t* vals)
+                     uint32_t* vals, bool key16)
 {
-    hipLaunchKernelGGL(k_duplicate, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
-                       g.tiles_touched, g.rect, (uint32_t)gridx, keys, vals);
+    if (key16)
+        hipLaunchKernelGGL(k_duplicate<uint16_t>, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
+                           g.tiles_touched, g.rect, (uint32_t)gridx, (uint16_t*)keys, vals);
+    else
+        hipLaunchKernelGGL(k_duplicate<uint32_t>, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
+                           g.tiles_touched, g.rect, (uint32_t)gridx, keys, vals);
     return check_launch(L, "duplicate");
 }
 
-__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= R) return;
@@ -93,11 +99,15 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const uint32_t* 
     if (idx == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T)
+int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T, bool key16)
 {
     if (hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), L.stream) != hipSuccess) return GSR_ERR_HIP;
     if (R > 0) {
-        hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R, sorted_keys, ranges);
+        if (key16)
+            hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R,
+                               (const uint16_t*)sorted_keys, ranges);
+        else
+            hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R, sorted_keys, ranges);
         return check_launch(L, "tile_ranges");
     }
     return GSR_OK;

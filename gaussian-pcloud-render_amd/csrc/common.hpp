@@ -56,7 +56,7 @@ struct GeomView {
 };
 
 struct BinView {
-    uint32_t* key[2];  // [R] tile ids, ping-pong
+    uint32_t* key[2];  // [R] tile ids, ping-pong (stored as uint16_t when the image has <= 65536 tiles)
     uint32_t* val[2];  // [R] Gaussian ids, ping-pong
     uint32_t* hist;    // [RADIX * nblk(R)]
     uint32_t* totals;  // [RADIX]
@@ -162,14 +162,16 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, i
 int launch_recolor(const Launch& L, const gsr_params& p, const GeomView& g);
 int launch_mark_visible(const Launch& L, int P, const float* means3D, const float* view, uint8_t* present);
 // sort.hip
+// key16: the key arrays hold uint16_t (tile ids of images up to 65536 tiles: 14 instead of 20 B per pair per pass)
 int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32_t* val[2], bool iota_vals,
-                            int end_bit, uint32_t* hist, uint32_t* totals, int* result_buffer);
+                            int end_bit, uint32_t* hist, uint32_t* totals, int* result_buffer, bool key16 = false);
+inline bool tile_keys16(int T) { return T <= 65536; }
 int launch_offsets_scan(const Launch& L, int P, const uint32_t* order, const uint32_t* tiles_touched,
                         uint32_t* dup_offset, uint32_t* scan_tmp, uint64_t* total_out);
 // binning.hip
 int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
-                     uint32_t* vals);
-int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T);
+                     uint32_t* vals, bool key16);
+int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T, bool key16);
 int launch_tile_order(const Launch& L, const ImageView& iv, int T, bool by_need);
 // render_fwd.hip / render_bwd.hip
 int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,

@@ -46,7 +46,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 // ---- pass kernel 1: digit histogram per workgroup ------------------------------------------------
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n, int shift,
+template <typename KeyT>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restrict__ keys, int64_t n, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ hist, int nblk)
 {
     __shared__ uint32_t h[RS_WAVES][RADIX];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const int64_t idx = base + i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[w][(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) atomicAdd(&h[w][((uint32_t)keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
     const uint32_t d = threadIdx.x;
@@ -82,10 +83,10 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 }
 
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
-template <int BITS>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ keys_in,
+template <int BITS, typename KeyT>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index
-                                                              uint32_t* __restrict__ keys_out,
+                                                              KeyT* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ totals, int nblk)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
     for (int j = 0; j < RS_ITEMS; j++) {
         const int64_t idx = seg_base + j * 64 + lane;
         const bool ok = idx < n;
-        k[j] = ok ? keys_in[idx] : 0xFFFFFFFFu;
+        k[j] = ok ? (uint32_t)keys_in[idx] : 0xFFFFFFFFu;
         v[j] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
     }
     __builtin_amdgcn_wave_barrier();
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
             const uint32_t key = s_key[p];
             const uint32_t d = (key >> shift) & mask;
             const size_t g = (size_t)global_base[d] + (p - local_base[d]);
-            keys_out[g] = key;
+            keys_out[g] = (KeyT)key;
             vals_out[g] = s_val[p];
         }
     }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
 // Sorts on key bits [0, end_bit).  key[0]/val[0] hold the input (val[0] ignored when iota_vals); the
 // result lands in key[*result_buffer] / val[*result_buffer].
 int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32_t* val[2], bool iota_vals, int end_bit,
-                            uint32_t* hist, uint32_t* totals, int* result_buffer)
+                            uint32_t* hist, uint32_t* totals, int* result_buffer, bool key16)
 {
     int cur = 0;
     if (n > 0) {
@@ -192,15 +193,26 @@ int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32
         for (int pass = 0; pass < npass; pass++) {
             const int bits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);   // even split, wider digits first
             const uint32_t mask = (1u << bits) - 1u;
-            hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(RS_THREADS), 0, L.stream, key[cur], n, shift, mask, hist, nblk);
+            if (key16)
+                hipLaunchKernelGGL(k_radix_hist<uint16_t>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, (const uint16_t*)key[cur], n,
+                                   shift, mask, hist, nblk);
+            else
+                hipLaunchKernelGGL(k_radix_hist<uint32_t>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, (const uint32_t*)key[cur], n,
+                                   shift, mask, hist, nblk);
             if (int e = check_launch(L, "radix_hist")) return e;
             hipLaunchKernelGGL(k_radix_rowscan, dim3(RADIX), dim3(256), 0, L.stream, hist, totals, nblk);
             if (int e = check_launch(L, "radix_rowscan")) return e;
             const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)val[cur];
-#define GSR_SCATTER(B)                                                                                                   \
-    case B:                                                                                                              \
-        hipLaunchKernelGGL(k_radix_scatter<B>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, key[cur], vin, key[cur ^ 1],  \
-                           val[cur ^ 1], n, shift, mask, hist, totals, nblk);                                            \
+#define GSR_SCATTER(B)                                                                                                     \
+    case B:                                                                                                                \
+        if (key16)                                                                                                         \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t>), dim3(nblk), dim3(RS_THREADS), 0, L.stream,                  \
+                               (const uint16_t*)key[cur], vin, (uint16_t*)key[cur ^ 1], val[cur ^ 1], n, shift, mask, hist, \
+                               totals, nblk);                                                                              \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t>), dim3(nblk), dim3(RS_THREADS), 0, L.stream,                  \
+                               (const uint32_t*)key[cur], vin, key[cur ^ 1], val[cur ^ 1], n, shift, mask, hist, totals,   \
+                               nblk);                                                                                      \
         break;
             switch (bits) {
                 GSR_SCATTER(1) GSR_SCATTER(2) GSR_SCATTER(3) GSR_SCATTER(4) GSR_SCATTER(5) GSR_SCATTER(6) GSR_SCATTER(7)

@@ -66,6 +66,19 @@ def render_views(render_one, n_views, dst=0, group=None):
     return gather_frames(torch.stack(frames, 0), n_views, dst=dst, group=group)
 
 
+_STREAMS = {}
+
+
+def _worker_streams(device, n):
+    """The worker streams are kept for the life of the process: torch's caching allocator pools memory per stream, so
+    fresh streams on every call would start with empty pools and pay hipMalloc (a device-wide sync) for every arena of
+    their first frames."""
+    key = (str(torch.device(device)), n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _STREAMS[key]
+
+
 def run_frames_pipelined(render, first, count, n_inflight, on_frame=None, device=None):
     """Keep `n_inflight` independent frames in flight on one GPU.
 
@@ -88,7 +101,7 @@ def run_frames_pipelined(render, first, count, n_inflight, on_frame=None, device
                 on_frame(i, img)
         return
     use_cuda = device is not None and torch.device(device).type == "cuda"
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)] if use_cuda else [None] * n_inflight
+    streams = _worker_streams(device, n_inflight) if use_cuda else [None] * n_inflight
     errs = []
     ready = {i: threading.Event() for i in range(first, first + count)}
     frames = {}
