@@ -36,14 +36,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 
 def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
     """Minimum HBM bytes each step of the pipeline has to move (per frame).  Render / preprocess figures are
-    SURVEY.md 8(d)'s; the sort figures follow this library's own data flow (u32 keys, u32 ids)."""
+    SURVEY.md 8(d)'s; the sort figures follow this library's own data flow (u32 depth keys and ids; tile keys are
+    u16 for images of up to 65536 tiles)."""
     b = {}
+    kb = 2 if T <= 65536 else 4
     b["preprocess"] = (44 + 12 * K) * P + 75 * V + 8 * (P - V)
     b["depth_sort"] = 4 * (4 + 8 + 8) * P
     b["offsets_scan"] = 3 * 8 * P
-    b["duplicate"] = 20 * P + 8 * R
-    b["tile_sort"] = tile_passes * (4 + 8 + 8) * R
-    b["tile_ranges"] = 4 * R + 16 * T
+    b["duplicate"] = 20 * P + (kb + 4) * R
+    b["tile_sort"] = tile_passes * (kb + 2 * (kb + 4)) * R
+    b["tile_ranges"] = kb * R + 16 * T
     b["render_forward"] = 40 * C_fwd + 8 * T + 20 * N
     b["render_backward"] = 40 * C_bwd + 20 * N + 44 * V
     b["preprocess_backward"] = 92 * V + (107 + 12 * K) * V + (40 + 12 * K) * V

@@ -197,11 +197,11 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
     {
         ProfScope ps("tile_ranges", L.stream);
         if (int e = launch_tile_ranges(L, R, b.key[res], iv.ranges, T, tile_keys16(T))) return e;
-        if (int e = launch_tile_order(L, iv, T, false)) return e;
+        if (int e = launch_tile_order(L, iv, T)) return e;
     }
     {
         ProfScope ps("render_forward", L.stream);
-        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color)) return e;
+        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color, p->need_backward ? b.ckpt : nullptr)) return e;
     }
     return GSR_OK;
 }
@@ -233,7 +233,7 @@ int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, cons
     }
     {
         ProfScope ps("render_forward", L.stream);
-        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color)) return e;
+        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color, nullptr)) return e;
     }
     return GSR_OK;
 }
@@ -259,12 +259,12 @@ int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* g
     const int passes = (tile_bits(tile_count(p)) + RADIX_BITS - 1) / RADIX_BITS;
     const int res = R > 0 ? (passes & 1) : 0;
     {
-        ProfScope ps("tile_order_bwd", L.stream);
-        if (int e = launch_tile_order(L, iv, tile_count(p), true)) return e;
+        ProfScope ps("bwd_items", L.stream);
+        if (int e = launch_bwd_items(L, iv, tile_count(p))) return e;
     }
     {
         ProfScope ps("render_backward", L.stream);
-        if (int e = launch_render_backward(L, *p, g, b.val[res], iv, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor)) return e;
+        if (int e = launch_render_backward(L, *p, g, b.val[res], iv, b.ckpt, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor)) return e;
     }
     {
         ProfScope ps("preprocess_backward", L.stream);

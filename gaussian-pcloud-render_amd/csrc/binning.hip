@@ -115,8 +115,7 @@ int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, 
 
 // ---- render launch order: tiles by descending work estimate (128 quarter-octave buckets) -------------
 // Per-tile work is (entries walked) x 256 pixels and the spread is 5-10x; dispatching the
-// heavy tiles first keeps the tail of the render kernels short.  The forward pass only knows the list length;
-// the backward pass knows exactly how many entries each tile consumed (tile_need, written by the forward).
+// heavy tiles first keeps the tail of the forward render kernel short (it only knows the list length).
 // Any permutation is correct.
 constexpr int ORD_BUCKETS = 128;
 
@@ -132,8 +131,7 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 // One 1024-thread workgroup: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
 // wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
 // one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
-__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, const uint32_t* __restrict__ need,
-                                                     uint32_t* __restrict__ tile_order)
+__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order)
 {
     __shared__ uint32_t cnt[ORD_BUCKETS];
     __shared__ uint32_t cur[ORD_BUCKETS];
@@ -146,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
         for (int t = threadIdx.x; t < T_pad; t += 1024) {
             const bool ok = t < T;
             uint32_t b = 0;
-            if (ok) b = work_bucket(need ? need[t] : ranges[t].y - ranges[t].x);
+            if (ok) b = work_bucket(ranges[t].y - ranges[t].x);
             const bool empty = ok && b == ORD_BUCKETS - 1;
             const uint64_t em = __ballot(empty);
             uint32_t slot = 0;
@@ -181,12 +179,68 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
     }
 }
 
-int launch_tile_order(const Launch& L, const ImageView& iv, int T, bool by_need)
+int launch_tile_order(const Launch& L, const ImageView& iv, int T)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, L.stream, T, iv.ranges,
-                       by_need ? (const uint32_t*)iv.tile_need : (const uint32_t*)nullptr,
-                       by_need ? iv.tile_order_bwd : iv.tile_order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, L.stream, T, iv.ranges, iv.tile_order);
     return check_launch(L, "tile_order");
+}
+
+// ---- backward work items ----------------------------------------------------------------------------------
+// The forward render recorded how many entries each tile consumed (tile_need).  That consumed prefix is cut into
+// chunks of BWD_CHUNK entries; each (tile, chunk) is an independent backward work item (the forward left the per-pixel
+// state at every chunk boundary), so the longest serial walk in the backward kernel is BWD_CHUNK entries instead of a
+// whole list.  Items are emitted heaviest first with the same bucket scheme as tile_order; a tile's chunk number
+// BWD_MAX_CHUNKS-1 takes everything that is left.  item = tile | chunk << 20.
+__global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,
+                                                    uint32_t* __restrict__ count)
+{
+    __shared__ uint32_t cnt[ORD_BUCKETS];
+    __shared__ uint32_t cur[ORD_BUCKETS];
+    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x < ORD_BUCKETS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t full_bucket = work_bucket(BWD_CHUNK);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int t = threadIdx.x; t < T; t += 1024) {
+            const uint32_t n = need[t];
+            if (n == 0) continue;
+            uint32_t n_full = n >> BWD_CHUNK_SHIFT;
+            if (n_full > BWD_MAX_CHUNKS - 1) n_full = BWD_MAX_CHUNKS - 1;
+            const uint32_t rest = n - (n_full << BWD_CHUNK_SHIFT);   // size of the tile's last item (may exceed BWD_CHUNK)
+            if (pass == 0) {
+                if (n_full) atomicAdd(&cnt[full_bucket], n_full);
+                if (rest) atomicAdd(&cnt[work_bucket(rest)], 1u);
+            } else {
+                if (n_full) {
+                    const uint32_t slot = atomicAdd(&cur[full_bucket], n_full);
+                    for (uint32_t c = 0; c < n_full; c++) items[slot + c] = (uint32_t)t | (c << 20);
+                }
+                if (rest) items[atomicAdd(&cur[work_bucket(rest)], 1u)] = (uint32_t)t | (n_full << 20);
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x < 64) {
+                const uint32_t a0 = cnt[2 * lane], a1 = cnt[2 * lane + 1];
+                uint32_t inc = a0 + a1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t n = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t)d) inc += n;
+                }
+                cur[2 * lane] = inc - a0 - a1;
+                cur[2 * lane + 1] = inc - a1;
+                if (lane == 63) count[0] = inc;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int launch_bwd_items(const Launch& L, const ImageView& iv, int T)
+{
+    hipLaunchKernelGGL(k_bwd_items, dim3(1), dim3(1024), 0, L.stream, T, iv.tile_need, iv.bwd_items, iv.bwd_count);
+    return check_launch(L, "bwd_items");
 }
 
 }  // namespace gsr

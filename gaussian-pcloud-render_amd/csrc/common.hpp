@@ -55,11 +55,19 @@ struct GeomView {
     size_t bytes;
 };
 
+// Backward work items: a tile's consumed list is cut into chunks of BWD_CHUNK entries that different waves walk
+// concurrently; the forward pass leaves the per-pixel state (T, accumulated colour) at every chunk boundary it crosses.
+constexpr int BWD_CHUNK = 1024;
+constexpr int BWD_CHUNK_SHIFT = 10;
+constexpr int BWD_MAX_CHUNKS = 16;   // per tile; the last one takes whatever is left
+
 struct BinView {
     uint32_t* key[2];  // [R] tile ids, ping-pong (stored as uint16_t when the image has <= 65536 tiles)
     uint32_t* val[2];  // [R] Gaussian ids, ping-pong
     uint32_t* hist;    // [RADIX * nblk(R)]
     uint32_t* totals;  // [RADIX]
+    float4* ckpt;      // [(R / BWD_CHUNK + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
+                       // range.x + k * BWD_CHUNK, slot (range.x >> BWD_CHUNK_SHIFT) + k  (unique: lists do not overlap)
     size_t bytes;
 };
 
@@ -68,8 +76,10 @@ struct ImageView {
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
     uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
-    uint32_t* tile_order_bwd; // [T] tiles by descending consumed entries (backward render launch order)
-    uint32_t* tile_need;  // [T] entries walked by the forward render (instrumentation for the bytes model)
+    uint32_t* tile_need;  // [T] entries walked by the forward render
+    float* accum;         // [3N] colour accumulated by the forward render, without the background term
+    uint32_t* bwd_items;  // [BWD_MAX_CHUNKS * T] backward work items: tile | chunk << 20, heaviest first
+    uint32_t* bwd_count;  // [4] number of items
     size_t bytes;
 };
 
@@ -116,6 +126,7 @@ inline BinView bin_view(void* base, int64_t R)
     carve(cur, b.val[1], r);
     carve(cur, b.hist, RADIX * nblk);
     carve(cur, b.totals, (size_t)RADIX);
+    carve(cur, b.ckpt, (r / BWD_CHUNK + 2) * 256);
     b.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return b;
 }
@@ -130,8 +141,10 @@ inline ImageView image_view(void* base, int W, int H)
     carve(cur, v.final_T, N ? N : 1);
     carve(cur, v.n_contrib, N ? N : 1);
     carve(cur, v.tile_order, T ? T : 1);
-    carve(cur, v.tile_order_bwd, T ? T : 1);
     carve(cur, v.tile_need, T ? T : 1);
+    carve(cur, v.accum, 3 * (N ? N : 1));
+    carve(cur, v.bwd_items, (size_t)BWD_MAX_CHUNKS * (T ? T : 1));
+    carve(cur, v.bwd_count, (size_t)4);
     v.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return v;
 }
@@ -172,13 +185,15 @@ int launch_offsets_scan(const Launch& L, int P, const uint32_t* order, const uin
 int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
                      uint32_t* vals, bool key16);
 int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T, bool key16);
-int launch_tile_order(const Launch& L, const ImageView& iv, int T, bool by_need);
+int launch_tile_order(const Launch& L, const ImageView& iv, int T);
+int launch_bwd_items(const Launch& L, const ImageView& iv, int T);
 // render_fwd.hip / render_bwd.hip
+// ckpt: chunk-boundary state for the backward pass (NULL: not recorded, e.g. inference / colour-only re-render)
 int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                          const ImageView& iv, float* out_color);
+                          const ImageView& iv, float* out_color, float4* ckpt);
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                           float* dL_dopacity, float* dL_dcolor);
+                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* dL_dmean2D,
+                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor);
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
 // preprocess_bwd.hip
 int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,

@@ -5,10 +5,13 @@
 // walked back to front, entries at or beyond the pixel's n_contrib are skipped, T is rebuilt by dividing out
 // (1 - alpha), the same power/alpha skips apply, and nine partial derivatives come out of every contributing pair.
 //
-// Mapping (ours), same wave-autonomous scheme as render_fwd.hip: one wave64 = one 8x8 quadrant walks the list on
-// its own (64 entries per round gathered one per lane, exact-safe footprint test + ballot, four surviving entries
-// at a time broadcast with v_readlane), starting at the largest n_contrib of ITS 64 pixels: entries nobody in
-// the quadrant consumed are never touched.  No LDS, no barrier.
+// Mapping (ours), same wave-autonomous scheme as render_fwd.hip: one wave64 = one 8x8 quadrant walks list entries on
+// its own (64 entries per round gathered one per lane, exact-safe footprint test + ballot, surviving entries staged
+// in the wave's own LDS and read back four at a time), never beyond the largest n_contrib of ITS 64 pixels.  No barrier.
+// The unit of work is not a whole list but a slice of BWD_CHUNK consumed entries of a tile (binning.hip k_bwd_items):
+// the forward pass recorded every pixel's (T, accumulated colour) at the slice boundaries, which is all the reference's
+// back-to-front recurrences need to start in the middle, so the slices of a long list are walked concurrently and the
+// longest serial walk in this kernel is BWD_CHUNK entries.
 //
 // Where the reference issues 9 float atomicAdds per contributing PAIR (up to 256 pixels hammering one Gaussian),
 // the 4 x 9 partial sums of a group are reduced over the 64 lanes FIRST, by a transposed butterfly: at every
@@ -176,7 +179,10 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
 
 struct RenderBwdArgs {
     const uint2* ranges;
-    const uint32_t* tile_order;
+    const uint32_t* items;       // work items: tile | chunk << 20, heaviest first (binning.hip k_bwd_items)
+    const uint32_t* item_count;  // [1]
+    const float4* ckpt;          // forward state at chunk boundaries (render_fwd.hip)
+    const float* accum;          // [3N] forward accumulated colour without background
     const uint32_t* point_list;
     const Splat* splat;
     int W, H, gridx, num_tiles;
@@ -192,12 +198,15 @@ struct RenderBwdArgs {
 
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
-    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
-    // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
+    // Work items are (tile, chunk of BWD_CHUNK consumed list entries); a workgroup takes every (gridDim/32 * 8)-th item.
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of one item
+    // are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the item's list slice and Splat records
     // are fetched into that L2 once instead of four times.
-    const uint32_t order_slot = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
-    if (order_slot >= (uint32_t)a.num_tiles) return;
-    const uint32_t tile = a.tile_order[order_slot];
+    const uint32_t n_items = a.item_count[0];
+    __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
+  for (uint32_t item_idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u); item_idx < n_items; item_idx += (gridDim.x >> 5) * 8u) {
+    const uint32_t item = a.items[item_idx];
+    const uint32_t tile = item & 0xFFFFFu, chunk = item >> 20;
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
@@ -220,11 +229,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         }
         total = (int)m;
     }
-    if (total == 0) return;
+    // this item's slice of the list: entries [lo, hi0), walked last first
+    const int lo = (int)(chunk << BWD_CHUNK_SHIFT);
+    if (lo >= total) continue;
+    const bool last_chunk = chunk == BWD_MAX_CHUNKS - 1 || lo + BWD_CHUNK >= total;
+    const int hi0 = last_chunk ? total : lo + BWD_CHUNK;
 
     const uint2 range = a.ranges[tile];
     const float T_final = inside ? a.final_T[pix] : 0.f;
-    float T = T_final;
     float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
     if (inside) {
         dpx0 = a.dL_dpix[pix];
@@ -261,23 +273,35 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 
     // the staging area starts as zeros, so slots of a partly filled last group always hold finite values (their
     // opacity is set to 0 every round, which is what keeps them from ever hitting)
-    __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
 #pragma unroll
     for (int i = 0; i < 16 * QUAD_WORDS / 64; i++) stage[i * 64 + lane] = 0.f;
 
+    // Per-pixel state at the back end of the slice.  A pixel whose last contributor lies inside (or before) the slice
+    // starts from its final state exactly like the reference; a pixel that also consumed entries behind the slice
+    // starts from what the forward pass recorded at the boundary hi0: T as it was there, and the colour accumulated
+    // behind it, (C_final - C_boundary) / T_boundary, which is what the reference's accum_rec recurrence would have
+    // built up by the time it reaches this entry (last_alpha = 0 makes the first update take it over unchanged).
+    float T = T_final;
     float s_rec = 0.f;                        // accum_rec . dL_dpixel
     float last_alpha = 0.f, last_d = 0.f;     // last alpha, last_color . dL_dpixel
+    if (!last_chunk && last_contributor > (uint32_t)hi0) {
+        const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)(hi0 >> BWD_CHUNK_SHIFT);
+        const float4 ck = a.ckpt[slot * 256 + q * 64 + lane];
+        T = ck.x;
+        const float behind = (a.accum[pix] - ck.y) * dpx0 + (a.accum[N + pix] - ck.z) * dpx1 + (a.accum[2 * N + pix] - ck.w) * dpx2;
+        s_rec = behind / ck.x;
+    }
 
     const uint32_t* plist = a.point_list + range.x;
-    // Round r covers front indices hi-64 .. hi-1 (hi = total - 64 r), lane i <-> f = hi-1-i, so the lowest set bit of
-    // the ballot is the entry nearest the back.  Lanes whose f would be negative re-read entry 0 and are masked.
+    // Round r covers front indices hi-64 .. hi-1 (hi = hi0 - 64 r), lane i <-> f = hi-1-i, so the lowest set bit of
+    // the ballot is the entry nearest the back.  Lanes whose f would fall before the slice re-read entry lo and are masked.
     f32x4 c0, c1, n0, n1;
     float c2b, n2b;  // blue
     uint32_t id_cur, id_nxt, id_nn;
     {
-        const int f0 = total - 1 - (int)lane, f1 = total - 65 - (int)lane;
-        bw_prefetch4(id_cur, plist + (f0 >= 0 ? f0 : 0));
-        bw_prefetch4(id_nxt, plist + (f1 >= 0 ? f1 : 0));
+        const int f0 = hi0 - 1 - (int)lane, f1 = hi0 - 65 - (int)lane;
+        bw_prefetch4(id_cur, plist + (f0 >= lo ? f0 : lo));
+        bw_prefetch4(id_nxt, plist + (f1 >= lo ? f1 : lo));
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
         const Splat* sp = a.splat + id_cur;
         bw_prefetch16(c0, &sp->q0);
@@ -285,17 +309,17 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         bw_prefetch4f(c2b, &sp->q2);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2b)::"memory");
     }
-    for (int hi = total; hi > 0; hi -= 64) {
+    for (int hi = hi0; hi > lo; hi -= 64) {
         {
             const Splat* sp = a.splat + id_nxt;
             bw_prefetch16(n0, &sp->q0);
             bw_prefetch16(n1, &sp->q1);
             bw_prefetch4f(n2b, &sp->q2);
             const int f2 = hi - 129 - (int)lane;
-            bw_prefetch4(id_nn, plist + (f2 >= 0 ? f2 : 0));
+            bw_prefetch4(id_nn, plist + (f2 >= lo ? f2 : lo));
         }
         const int f_lane = hi - 1 - (int)lane;
-        const bool touch = f_lane >= 0 && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
+        const bool touch = f_lane >= lo && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
         uint64_t mask = __ballot(touch);
 
         if (mask != 0) {
@@ -418,15 +442,19 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         id_cur = id_nxt;
         id_nxt = id_nn;
     }
+  }
 }
 
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                            float* dL_dopacity, float* dL_dcolor)
 {
     RenderBwdArgs a;
     a.ranges = iv.ranges;
-    a.tile_order = iv.tile_order_bwd;
+    a.items = iv.bwd_items;
+    a.item_count = iv.bwd_count;
+    a.ckpt = ckpt;
+    a.accum = iv.accum;
     a.point_list = point_list;
     a.splat = g.splat;
     a.W = p.W; a.H = p.H;
@@ -441,6 +469,8 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView&
     a.dL_dopacity = dL_dopacity;
     a.dL_dcolor = dL_dcolor;
     a.num_tiles = a.gridx * gridy;
+    // the number of items is only known on the device: a grid of one workgroup quartet per tile (as many wave slots as
+    // the chip has several times over) walks the item list with a stride
     hipLaunchKernelGGL(k_render_backward, dim3((unsigned)div_up(a.num_tiles, 8) * 32u), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_backward");
 }

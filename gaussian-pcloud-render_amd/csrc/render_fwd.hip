@@ -36,6 +36,8 @@ struct RenderArgs {
     float* final_T;
     uint32_t* n_contrib;
     uint32_t* tile_need;
+    float4* ckpt;   // chunk-boundary state for the backward pass, or NULL
+    float* accum;   // [3N] accumulated colour without background (only written with ckpt)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -194,6 +196,12 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 prefetch4(id_nn, plist + (i2 < total ? i2 : last));
             }
 
+            // backward work items are chunks of BWD_CHUNK list entries: leave this quadrant's state at the boundaries it crosses
+            if (a.ckpt != nullptr && base != 0 && (base & (BWD_CHUNK - 1)) == 0 && (base >> BWD_CHUNK_SHIFT) < BWD_MAX_CHUNKS) {
+                const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)(base >> BWD_CHUNK_SHIFT);
+                a.ckpt[slot * 256 + q * 64 + lane] = make_float4(T, C01.x, C01.y, C2);
+            }
+
             // which of this round's 64 entries can reach alpha >= 1/255 somewhere in this quadrant?
             const bool valid = base + (int)lane < total;
             const bool touch = valid && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
@@ -312,11 +320,16 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         a.out_color[pix] = C01.x + T * a.bg[0];
         a.out_color[N + pix] = C01.y + T * a.bg[1];
         a.out_color[2 * N + pix] = C2 + T * a.bg[2];
+        if (a.ckpt != nullptr) {
+            a.accum[pix] = C01.x;
+            a.accum[N + pix] = C01.y;
+            a.accum[2 * N + pix] = C2;
+        }
     }
 }
 
 int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                          const ImageView& iv, float* out_color)
+                          const ImageView& iv, float* out_color, float4* ckpt)
 {
     RenderArgs a;
     a.ranges = iv.ranges;
@@ -331,6 +344,8 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& 
     a.final_T = iv.final_T;
     a.n_contrib = iv.n_contrib;
     a.tile_need = iv.tile_need;
+    a.ckpt = ckpt;
+    a.accum = iv.accum;
     const int T = a.gridx * gridy;
     if (hipMemsetAsync(iv.tile_need, 0, (size_t)T * sizeof(uint32_t), L.stream) != hipSuccess) return GSR_ERR_HIP;
     a.num_tiles = T;
