@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+VALU_PEAK_GWIPS = 1228.9  # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
 
 
 def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
@@ -212,10 +213,13 @@ def main():
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
         roofline = None
         traffic = None
+        valu = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KiB -> B)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get("bytes_per_launch", {}).get({"render_backward": "k_render_backward",
-                                                                          "render_forward": "k_render_forward"}.get(dom, dom))
+                pmc = json.load(f)
+            kname = {"render_backward": "k_render_backward", "render_forward": "k_render_forward"}.get(dom, dom)
+            traffic = pmc.get("bytes_per_launch", {}).get(kname)
+            valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
         except (OSError, ValueError):
             traffic = None
         if dom is not None:
@@ -223,6 +227,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes": int(bytes_per[dom]), "avg_ms": round(avg_ms[dom], 4)}
+            if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
+                rate = valu / (avg_ms[dom] * 1e-3)
+                roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
+                                    "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
+                                    "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json"}
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
         frame_gpu_ms = sum(avg_ms.values())
 

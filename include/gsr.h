@@ -61,7 +61,9 @@ typedef struct gsr_params {
     float scale_modifier;
     int prefiltered;
     int debug;
-    int need_backward;     /* 0: inference call, skip the saves only backward reads (clamped mask)   */
+    int need_backward;     /* 0: inference call, skip the saves only gsr_backward reads (SH clamp mask,
+                              accumulated colour, per-pixel state at the 1024-entry list boundaries);
+                              gsr_backward is only valid after a forward with need_backward = 1      */
     const float* bg;             /* [3]        device */
     const float* means3D;        /* [P,3]      device */
     const float* shs;            /* [P,M,3]    device or NULL */
