@@ -116,7 +116,21 @@ __device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const floa
 __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    if (idx >= a.P) return;
+    if (!(a.radii[idx] > 0)) {
+        // invisible Gaussian: no gradient.  The per-Gaussian outputs this kernel owns are written for every index, so the
+        // caller does not have to clear them first (the atomically accumulated ones and dL_dsh's unused rows it does).
+#pragma unroll
+        for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+        if (a.scales) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.f;
+            *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
 
     float view[16], proj[16];
 #pragma unroll

@@ -140,12 +140,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     device = means3D.device
     _require_hip(device)
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
-    radii = torch.zeros((P,), dtype=torch.int32, device=device)
     byte = dict(dtype=torch.uint8, device=device)
     if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
         e = torch.empty((0,), **byte)
-        return 0, out_color, radii, e, e.clone(), e.clone()
+        return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
+                e, e.clone(), e.clone())
+    # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((P,), dtype=torch.int32, device=device)
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
         p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -196,15 +198,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
     M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0
     z = dict(dtype=torch.float32, device=device)
-    dL_dmeans3D = torch.zeros((P, 3), **z)
+    # atomically accumulated outputs and dL_dsh (unused rows stay zero) are cleared; the rest is written for every Gaussian
+    # by the per-Gaussian backward kernel (see include/gsr.h), so clearing them first would only cost bandwidth
+    has_sr = scales.numel() != 0 and P != 0
+    dL_dmeans3D = torch.empty((P, 3), **z) if P != 0 else torch.zeros((P, 3), **z)
     dL_dmeans2D = torch.zeros((P, 3), **z)
     dL_dcolors = torch.zeros((P, 3), **z)
     dL_dconic = torch.zeros((P, 2, 2), **z)
     dL_dopacity = torch.zeros((P, 1), **z)
-    dL_dcov3D = torch.zeros((P, 6), **z)
+    dL_dcov3D = torch.empty((P, 6), **z) if P != 0 else torch.zeros((P, 6), **z)
     dL_dsh = torch.zeros((P, M, 3), **z)
-    dL_dscales = torch.zeros((P, 3), **z)
-    dL_drotations = torch.zeros((P, 4), **z)
+    dL_dscales = torch.empty((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
+    dL_drotations = torch.empty((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
