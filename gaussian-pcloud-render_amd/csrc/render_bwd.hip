@@ -376,32 +376,35 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             }
             if (!__any(any_lane_hit)) continue;
 
-            // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.  A lane that does not
-            // hit multiplies T by exactly 1 and keeps its state.
+            // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.
             // The reference tracks accum_rec[ch], the colour accumulated behind the current entry, only to form
             // sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  That sum is linear, so the same recurrence is run on the
             // scalar s = accum_rec . dL_dpixel and d = c . dL_dpixel (7 operations per entry instead of 18); fused
             // multiply-adds are allowed from here on (gradients are compared to tolerance; power / alpha above are not
             // touched, so hit decisions stay those of the forward pass).
+            // A lane that does not hit runs the same update with alpha := 0, which is exact: T is multiplied by
+            // rcp(1) = 1, its colour weight alpha*T is 0, and the pending pair (last_alpha, last_d) it leaves behind,
+            // (0, d), makes the next fold s + 0*(d - s) return s unchanged, while the pair it replaces has just been folded
+            // into s exactly as the next hit would have done.  One select instead of five.
             float dLa[BGRP], Gh[BGRP], dch[BGRP];
 #pragma unroll
             for (int k = 0; k < BGRP; k++) {
                 const bool hit = hits[k];
-                const float alpha = alphas[k];
+                const float alpha = hit ? alphas[k] : 0.f;
                 const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = T * (hit ? rcp : 1.0f);
+                const float Tn = T * rcp;
                 const float d = __builtin_fmaf(eb[k], dpx2, __builtin_fmaf(eg[k], dpx1, er[k] * dpx0));
                 const float sn = __builtin_fmaf(last_alpha, last_d - s_rec, s_rec);  // la*last_d + (1-la)*s
                 float dL_dalpha = (d - sn) * Tn;
                 dL_dalpha = __builtin_fmaf(-T_final * rcp, bg_dot_dpixel, dL_dalpha);
-                // lanes that do not hit contribute exact zeros: three selects zero every product of phase 2
+                // lanes that do not hit contribute exact zeros to every product of phase 2
                 dLa[k] = hit ? dL_dalpha : 0.f;
                 Gh[k] = hit ? Gs[k] : 0.f;
-                dch[k] = hit ? alpha * Tn : 0.f;
+                dch[k] = alpha * Tn;
                 T = Tn;
-                s_rec = hit ? sn : s_rec;
-                last_d = hit ? d : last_d;
-                last_alpha = hit ? alpha : last_alpha;
+                s_rec = sn;
+                last_d = d;
+                last_alpha = alpha;
             }
             // Phase 2: the 4 x 9 partial derivatives of this lane's pixel, again on entry pairs
             float v[32], xo[BGRP];
