@@ -133,6 +133,16 @@ def build_scene(name):
         g = synth.random_scene(2500, W, H, seed=12, sh_degree=1, spread=1.5, scale=0.25)
         g["opacities"] *= 0.35
         return scene_from(g, identity_camera(W, H), W, H, bg=(0.9, 0.8, 0.7))
+    if name == "deep_stack":             # one 20 000-entry list that no pixel ever terminates: more than BWD_MAX_CHUNKS slices
+        W, H = 24, 16                    # (two tiles, one of them partial)
+        rng = np.random.default_rng(13)
+        P = 20000
+        means = np.stack([rng.uniform(-0.25, 0.25, P), rng.uniform(-0.2, 0.2, P), rng.uniform(1.0, 3.0, P)], 1).astype(np.float32)
+        g = dict(means3D=means, scales=np.exp(rng.normal(np.log(0.08), 0.3, (P, 3))).astype(np.float32),
+                 rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1)),
+                 opacities=rng.uniform(0.004, 0.0075, (P, 1)).astype(np.float32),   # alpha hovers around the 1/255 cut
+                 shs=(0.6 * rng.standard_normal((P, 4, 3))).astype(np.float32), sh_degree=1)
+        return scene_from(g, identity_camera(W, H), W, H, bg=(0.2, 0.3, 0.4))
     if name == "one_gaussian":
         W, H = 33, 17
         g = dict(means3D=np.array([[0.05, -0.02, 1.5]], np.float32), scales=np.array([[0.2, 0.05, 0.1]], np.float32),
@@ -144,7 +154,7 @@ def build_scene(name):
 
 SCENES = ["random_aniso", "sh_deg0", "sh_deg1", "sh_deg2", "sh_deg3", "colors_precomp", "cov3d_precomp",
           "scale_modifier", "culled_mix", "all_culled", "voxel_ties", "opaque_early_stop", "capsule_circle",
-          "capsule_axis_view", "big_splats", "one_gaussian"]
+          "capsule_axis_view", "big_splats", "deep_stack", "one_gaussian"]
 
 
 def seeded_dL(scene, seed=123):
