@@ -198,16 +198,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
     M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0
     z = dict(dtype=torch.float32, device=device)
-    # atomically accumulated outputs and dL_dsh (unused rows stay zero) are cleared; the rest is written for every Gaussian
-    # by the per-Gaussian backward kernel (see include/gsr.h), so clearing them first would only cost bandwidth
+    # Atomically accumulated outputs and dL_dsh (unused rows stay zero) are cleared -- as slices of ONE zero-filled
+    # allocation, so the clearing is one fill kernel instead of five; the rest is written for every Gaussian by the
+    # per-Gaussian backward kernel (see include/gsr.h), so clearing them first would only cost bandwidth.
     has_sr = scales.numel() != 0 and P != 0
+    sizes = (3 * P, 3 * P, 4 * P, P, 3 * M * P)
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64          # keep every slice 256-B aligned
+    flat = torch.zeros((total,), **z)
+    dL_dmeans2D = flat[offs[0]:offs[0] + sizes[0]].view(P, 3)
+    dL_dcolors = flat[offs[1]:offs[1] + sizes[1]].view(P, 3)
+    dL_dconic = flat[offs[2]:offs[2] + sizes[2]].view(P, 2, 2)
+    dL_dopacity = flat[offs[3]:offs[3] + sizes[3]].view(P, 1)
+    dL_dsh = flat[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
     dL_dmeans3D = torch.empty((P, 3), **z) if P != 0 else torch.zeros((P, 3), **z)
-    dL_dmeans2D = torch.zeros((P, 3), **z)
-    dL_dcolors = torch.zeros((P, 3), **z)
-    dL_dconic = torch.zeros((P, 2, 2), **z)
-    dL_dopacity = torch.zeros((P, 1), **z)
     dL_dcov3D = torch.empty((P, 6), **z) if P != 0 else torch.zeros((P, 6), **z)
-    dL_dsh = torch.zeros((P, M, 3), **z)
     dL_dscales = torch.empty((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
     dL_drotations = torch.empty((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
