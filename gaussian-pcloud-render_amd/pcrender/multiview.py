@@ -88,6 +88,10 @@ def run_frames_pipelined(render, first, count, n_inflight, on_frame=None, device
     every n_inflight-th step on their own HIP stream: one frame's tail overlaps the next frame's bandwidth-bound
     stages (ctypes releases the GIL during the native calls, including the one stream sync per frame).
 
+    Every worker stream should get a hardware queue of its own: start the process with GPU_MAX_HW_QUEUES >= n_inflight + 2
+    (the ROCm default of 4 makes two of four workers' streams, or a worker and the caller's stream, share a queue and
+    serialise; bench.py sets 8).
+
     `on_frame(step, tensor)`, if given, is called on the CALLING thread, in increasing step order, after making the
     caller's stream wait for the frame - this is where collectives (the frame gather) belong, so that every rank
     issues them in the same order whatever the thread timing.  With device=None (CPU tests) no streams are used.
