@@ -105,17 +105,7 @@ __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x)
 // loads (s_load through the scalar cache) have the right cost but ~1 us latency, which the serial walk of the
 // longest lists cannot hide.  A wave owns its 2.5 KB of LDS: no barrier anywhere (DS operations of one wave execute
 // in order).
-constexpr int PAIR_WORDS = 20;  // 18 used, padded so each pair starts on a 16-B boundary
-
-// lowest one or two set bits of the survivor mask (the second defaults to the first when only one is left)
-__device__ __forceinline__ void take_pair(uint64_t& mask, int& j0, int& j1)
-{
-    j0 = (int)__builtin_ctzll(mask);
-    mask &= mask - 1;
-    const bool two = mask != 0;
-    j1 = two ? (int)__builtin_ctzll(mask) : j0;
-    mask = two ? (mask & (mask - 1)) : 0;
-}
+constexpr int PAIR_WORDS = 20;
 
 struct PairRec {
     f32x4 xy;   // x0 x1 y0 y1
@@ -123,6 +113,7 @@ struct PairRec {
     f32x4 co;   // C0 C1 o0 o1
     f32x4 rg;   // r0 g0 r1 g1
     f32x2 b;    // b0 b1
+    uint2 pos;  // 1-based list positions of the two entries
 };
 __device__ __forceinline__ PairRec read_pair(const float* lds, int pair)
 {
@@ -133,6 +124,7 @@ __device__ __forceinline__ PairRec read_pair(const float* lds, int pair)
     r.co = *(const f32x4*)(p + 8);
     r.rg = *(const f32x4*)(p + 12);
     r.b = *(const f32x2*)(p + 16);
+    r.pos = *(const uint2*)(p + 18);
     return r;
 }
 
@@ -217,19 +209,23 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                     float* pc = stage + (slot >> 1) * PAIR_WORDS + 12 + 2 * (slot & 1u);
                     pc[0] = c1.z; pc[1] = c1.w;
                     p[16] = c2b;
+                    const uint32_t my_pos = (uint32_t)(base + (int)lane + 1);   // 1-based list position
+                    uint32_t* pp = (uint32_t*)p;
+                    pp[18] = my_pos;
                     if (slot + 1 == nsurv && (slot & 1u) == 0) {
                         // odd count: the missing partner is a copy with opacity 0 -> alpha 0 -> the 1/255 test drops it
                         p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
                         pc[2] = c1.z; pc[3] = c1.w;
                         p[17] = c2b;
+                        pp[19] = my_pos;
                     }
                 }
                 // Pair p+1 is read from LDS while pair p is evaluated.  The loop body is written out twice with the two
                 // register sets swapped, so no register moves are needed to rotate them.
-                auto eval_pair = [&](const PairRec& r, int j0, int j1) {
+                auto eval_pair = [&](const PairRec& r) {
                     // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
                     // share packed fp32 instructions (v_pk_*_f32).
-                    const uint32_t eidx0 = (uint32_t)(base + j0 + 1), eidx1 = (uint32_t)(base + j1 + 1);  // 1-based list position
+                    const uint32_t eidx0 = r.pos.x, eidx1 = r.pos.y;
                     const f32x2 X = {r.xy.x, r.xy.y}, Y = {r.xy.z, r.xy.w}, A2 = {r.ab.x, r.ab.y}, B2 = {r.ab.z, r.ab.w};
                     const f32x2 C2p = {r.co.x, r.co.y}, O2 = {r.co.z, r.co.w};
                     const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
@@ -276,19 +272,17 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         all_done = __all(done);
                     }
                 };
+                const int npairs = (int)((nsurv + 1u) >> 1);
                 int pair = 0;
                 PairRec ra = read_pair(stage, 0), rb;  // rb is always read from LDS before it is evaluated
                 for (;;) {
-                    int j0, j1;
-                    take_pair(mask, j0, j1);
-                    bool more = mask != 0;
+                    bool more = pair + 1 < npairs;
                     if (more) rb = read_pair(stage, pair + 1);
-                    eval_pair(ra, j0, j1);
+                    eval_pair(ra);
                     if (!more || all_done) break;
-                    take_pair(mask, j0, j1);
-                    more = mask != 0;
+                    more = pair + 2 < npairs;
                     if (more) ra = read_pair(stage, pair + 2);
-                    eval_pair(rb, j0, j1);
+                    eval_pair(rb);
                     if (!more || all_done) break;
                     pair += 2;
                 }
