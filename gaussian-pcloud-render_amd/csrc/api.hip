@@ -21,6 +21,8 @@
 #include <vector>
 
 #include "common.hpp"
+#include <atomic>
+#include <mutex>
 
 namespace gsr {
 
@@ -48,7 +50,9 @@ struct ProfEntry {
     const char* name;
     int a, b;  // indices into the event pool
 };
-static bool g_prof_on = false;
+// (several host threads may render at once: the tables are guarded, the flag is atomic)
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<hipEvent_t> g_pool;
 static size_t g_pool_used = 0;
 static std::vector<ProfEntry> g_prof;
@@ -71,13 +75,19 @@ struct ProfScope {
     {
         if (!on) return;
         e.name = name;
-        e.a = pool_event();
-        e.b = pool_event();
-        (void)hipEventRecord(g_pool[e.a], s);
+        hipEvent_t ea;
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            e.a = pool_event();
+            e.b = pool_event();
+            ea = g_pool[e.a];
+        }
+        (void)hipEventRecord(ea, s);
     }
     ~ProfScope()
     {
         if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         (void)hipEventRecord(g_pool[e.b], s);
         g_prof.push_back(e);
     }
@@ -403,6 +413,7 @@ int gsr_selftest(gsr_stream_t stream)
 
 void gsr_set_profiling(int on)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
     g_prof.clear();
     g_pool_used = 0;
@@ -410,6 +421,7 @@ void gsr_set_profiling(int on)
 
 int gsr_get_profile(const char** names, float* ms, int cap)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
     for (auto& e : g_prof) {
         if (n >= cap) break;

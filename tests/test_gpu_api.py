@@ -179,3 +179,56 @@ def test_hostile_inputs_fail_cleanly_or_render_finite(gpu_device):
         big(means3D=mm, means2D=torch.zeros_like(mm), colors_precomp=torch.ones((P, 3), device=dev),
             opacities=torch.ones((P, 1), device=dev), scales=torch.full((P, 3), 100.0, device=dev),
             rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(P, 1))
+
+
+def test_concurrent_host_threads_get_the_sequential_result(gpu_device):
+    """Frames in flight: several host threads, each on its own stream, render different scenes at once (with the
+    per-stage profiler switched on and off from another thread meanwhile); every forward output must be byte-identical
+    to the sequential run and the gradients within the usual tolerance of it."""
+    import threading
+    import torch
+    from diff_gaussian_rasterization import _native as N
+    names = ["random_aniso", "big_splats", "capsule_circle", "voxel_ties"]
+    scenes = [util.build_scene(n) for n in names]
+    dLs = [util.seeded_dL(s) for s in scenes]
+    ref = [util.run_product(s, gpu_device, dL_dpix=d) for s, d in zip(scenes, dLs)]
+    errs = []
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream(device=gpu_device)
+            with torch.cuda.stream(st):
+                for it in range(12):
+                    k = (t + it) % len(scenes)
+                    p, g = util.run_product(scenes[k], gpu_device, dL_dpix=dLs[k])
+                    rp, rg = ref[k]
+                    assert p["R"] == rp["R"]
+                    assert p["out_color"].tobytes() == rp["out_color"].tobytes(), names[k]
+                    assert np.array_equal(p["vals"], rp["vals"]) and np.array_equal(p["n_contrib"], rp["n_contrib"])
+                    for key in g:
+                        if g[key].size:
+                            scale = np.abs(rg[key]).max()
+                            assert np.abs(g[key].astype(np.float64) - rg[key]).max() <= 2e-4 * scale + 1e-30, (names[k], key)
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    stop = threading.Event()
+
+    def toggler():
+        while not stop.is_set():
+            N.set_profiling(True)
+            N.get_profile()
+            N.set_profiling(False)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    tg = threading.Thread(target=toggler)
+    tg.start()
+    for x in ths:
+        x.start()
+    for x in ths:
+        x.join()
+    stop.set()
+    tg.join()
+    N.set_profiling(False)
+    assert not errs, errs[0]
