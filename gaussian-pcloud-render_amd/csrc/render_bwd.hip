@@ -130,11 +130,30 @@ __device__ __forceinline__ float reduce32_transposed(const float (&v)[32], uint3
     GSR_SWAP8("v_permlane16_swap_b32", a, b);
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = a[i] + b[i];
-    const bool b3 = (lane & 8u) != 0, b2 = (lane & 4u) != 0, b1 = (lane & 2u) != 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = (b3 ? s[i + 4] : s[i]) + xor8(b3 ? s[i] : s[i + 4]);
-#pragma unroll
-    for (int i = 0; i < 2; i++) u[i] = (b2 ? t[i + 2] : t[i]) + xor4(b2 ? t[i] : t[i + 2]);
+    const bool b1 = (lane & 2u) != 0;
+    // bit 3: lanes 0-7 of a row keep value i, lanes 8-15 keep value i+4; the partner (lane ^ 8 = row_ror:8) holds the other
+    // half of the same value.  The two cases are two DPP adds with complementary bank masks writing one register: no
+    // selects.  (s_nop: VALU write -> DPP read needs two wait states and hipcc pads nothing inside or around asm.)
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                 : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]));
+    // bit 2: banks 0,2 (lane & 4 == 0) keep value i and read lane+4 (row_shl:4), banks 1,3 keep value i+2 and read lane-4
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "s_nop 1"
+                 : "=&v"(u[0]), "=&v"(u[1])
+                 : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
     float w = (b1 ? u[1] : u[0]) + xor2(b1 ? u[0] : u[1]);
     w += xor1(w);
     return w;
@@ -397,8 +416,9 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 const float sn = __builtin_fmaf(last_alpha, last_d - s_rec, s_rec);  // la*last_d + (1-la)*s
                 float dL_dalpha = (d - sn) * Tn;
                 dL_dalpha = __builtin_fmaf(-T_final * rcp, bg_dot_dpixel, dL_dalpha);
-                // lanes that do not hit contribute exact zeros to every product of phase 2
-                dLa[k] = hit ? dL_dalpha : 0.f;
+                // lanes that do not hit contribute exact zeros: every product of phase 2 carries a factor Gh or alpha*T
+                // (dL_dalpha itself stays finite, so 0 * dL_dalpha is 0)
+                dLa[k] = dL_dalpha;
                 Gh[k] = hit ? Gs[k] : 0.f;
                 dch[k] = alpha * Tn;
                 T = Tn;
