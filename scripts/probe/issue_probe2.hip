@@ -25,6 +25,9 @@ KERNEL(k_rndne, "v_rndne_f32 %0, %0\n v_rndne_f32 %1, %1\n v_rndne_f32 %2, %2\n 
 KERNEL(k_cvt, "v_cvt_i32_f32 %4, %0\n v_cvt_i32_f32 %5, %1\n v_cvt_i32_f32 %4, %2\n v_cvt_i32_f32 %5, %3\n")
 KERNEL(k_fma, "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %0\n v_fma_f32 %3, %3, %0, %1\n")
 KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_swap32, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n")
+KERNEL(k_swap16, "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n")
+KERNEL(k_add_dpp, "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n")
 KERNEL(k_sand, "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_and_b64 s[22:23], s[20:21], s[22:23]\n s_and_b64 s[20:21], s[20:21], s[22:23]\n s_and_b64 s[22:23], s[20:21], s[22:23]\n")
 template <typename K> static void run(const char* name, K k, float* out)
 {
@@ -41,6 +44,6 @@ int main()
     run("add", k_add, out); run("fma", k_fma, out); run("min", k_min, out); run("and", k_and, out); run("ashr", k_ashr, out);
     run("cnd_vcc", k_cnd_vcc, out); run("cnd_e64", k_cnd_e64, out); run("cmp_vcc", k_cmp_vcc, out); run("cmp_e64", k_cmp_e64, out);
     run("cmp+cnd", k_cmp_cnd, out); run("rcp", k_rcp, out); run("ldexp", k_ldexp, out); run("rndne", k_rndne, out); run("cvt", k_cvt, out);
-    run("mov_dpp", k_mov_dpp, out); run("s_and", k_sand, out);
+    run("mov_dpp", k_mov_dpp, out); run("swap32", k_swap32, out); run("swap16", k_swap16, out); run("add_dpp", k_add_dpp, out); run("s_and", k_sand, out);
     return 0;
 }
