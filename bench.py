@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "4")),
                     help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --device-index 0 lets several ranks share one GPU to exercise the multi-rank control flow "
+                         "(frames then travel through host memory; not a performance mode)")
+    ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,11 +84,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device_index < 0 else args.device_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    host_collectives = args.dist_backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if host_collectives:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _native
     from pcrender import camera, multiview, synth
@@ -115,7 +124,8 @@ def main():
     means3D, shs, opac = leafsets[0]["means3D"], leafsets[0]["shs"], leafsets[0]["opacities"]
     scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
-    gather_list = [torch.empty((3, H, W), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_list = [torch.empty((3, H, W), device="cpu" if host_collectives else dev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
 
     do_gather = world > 1 and not args.no_gather
 
@@ -134,7 +144,7 @@ def main():
         return img
 
     def gather(img):
-        dist.gather(img, gather_list=gather_list, dst=0)
+        dist.gather(img.cpu() if host_collectives else img, gather_list=gather_list, dst=0)
 
     def step(i, tslot=0):
         img = render(i, tslot)
@@ -184,7 +194,7 @@ def main():
         single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1}
         kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % n1
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if host_collectives else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
