@@ -10,15 +10,18 @@
 //   - 64 list entries per round, one per lane: the lane gathers the entry's packed 48-B Splat record and
 //     decides with the exact-safe footprint test (tile_cull.hpp) whether the entry can matter to THIS quadrant;
 //     a ballot turns that into a 64-bit mask;
-//   - the mask is consumed four set bits at a time by scalar code (s_ff1 / s_and), the chosen lanes' records are
-//     broadcast with v_readlane into SGPRs, and the 64 pixels evaluate the four entries with scalar operands:
-//     no LDS, no barrier, no waiting for sibling quadrants (a quadrant of a silhouette tile that sees half the
-//     entries finishes in half the time and frees its SIMD slot);
+//   - the surviving lanes write their records (and the entries' list positions), compacted and interleaved in
+//     pairs, into 2.5 KB of LDS that belongs to the wave; the wave reads the pairs back with same-address ds_read, so
+//     the 64 pixels evaluate two entries at a time on packed fp32 instructions: no barrier (DS operations of one wave
+//     execute in order), no waiting for sibling quadrants (a quadrant of a silhouette tile that sees half the entries
+//     finishes in half the time and frees its SIMD slot);
 //   - the next round's records (and the ids of the round after) are already in flight while a round is
 //     evaluated, so the dependent id -> record gather latency is off the critical path;
 //   - per-pixel skips are selects; the only branches are wave-uniform (mask empty, all 64 pixels done).
-// The frame time of this kernel is set by the few longest lists (a wave walks its list serially); tiles are
-// dispatched in descending list-length order (tile_order) so those start first.
+// The duration of this kernel is set by the quadrants that walk deepest (a wave walks its list serially, one
+// instruction per ~5.5 cycles when it has its SIMD to itself); tiles are dispatched in descending list-length order
+// (tile_order).  With need_backward the per-pixel (T, C) state is left at every BWD_CHUNK-entry boundary a quadrant
+// crosses, so that the backward pass can work on slices of lists (render_bwd.hip).
 #include "common.hpp"
 #include "tile_cull.hpp"
 
