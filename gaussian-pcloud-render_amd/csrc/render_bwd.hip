@@ -338,9 +338,19 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             bw_prefetch4(id_nn, plist + (f2 >= lo ? f2 : lo));
         }
         const int f_lane = hi - 1 - (int)lane;
-        const bool touch = f_lane >= lo && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
-        uint64_t mask = __ballot(touch);
-
+        // only pixels whose last contributor lies beyond this round's first entry can be hit by the round: test
+        // the entries against their bounding rectangle (the deeper the slice, the fewer pixels are left)
+        const int round_lo = hi - 64 > lo ? hi - 64 : lo;
+        const uint64_t live = __ballot(last_contributor > (uint32_t)round_lo);
+        uint64_t mask = 0;
+        bool touch = false;
+        if (live != 0) {
+            int ax, ay, bx, by;
+            live_box(live, ax, ay, bx, by);
+            touch = f_lane >= lo && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f + (float)ax, y0f + (float)ay,
+                                                    x0f + (float)bx, y0f + (float)by);
+            mask = __ballot(touch);
+        }
         if (mask != 0) {
             const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const uint32_t nsurv = (uint32_t)__popcll(mask);

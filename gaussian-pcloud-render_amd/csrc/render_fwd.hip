@@ -147,6 +147,9 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixf_x = (float)px, pixf_y = (float)py;
     const float x0f = (float)x0, y0f = (float)y0;
+    // rectangle of the pixels that are still live (not outside the image, not terminated): the footprint test only has to
+    // keep entries that can reach one of those
+    float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 7.f;
 
     __shared__ __attribute__((aligned(16))) float stage[32 * PAIR_WORDS];
 
@@ -160,6 +163,11 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     uint32_t stop_at = 0;  // 1-based index of the entry that terminated this pixel
     bool done = !inside;
     bool all_done = __all(done);
+    if (!all_done) {
+        int ax, ay, bx, by;
+        live_box(__ballot(!done), ax, ay, bx, by);
+        bx0 = x0f + (float)ax; by0 = y0f + (float)ay; bx1 = x0f + (float)bx; by1 = y0f + (float)by;
+    }
 
     if (!all_done && total > 0) {
         const uint32_t* plist = a.point_list + range.x;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 
             // which of this round's 64 entries can reach alpha >= 1/255 somewhere in this quadrant?
             const bool valid = base + (int)lane < total;
-            const bool touch = valid && may_touch_8x8(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f, y0f);
+            const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx0, by0, bx1, by1);
             uint64_t mask = __ballot(touch);
 
             if (mask != 0) {
@@ -272,7 +280,13 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                             stop_at = stop ? ei_[k] : stop_at;
                             done = done || stop;
                         }
-                        all_done = __all(done);
+                        const uint64_t live = __ballot(!done);
+                        all_done = live == 0;
+                        if (!all_done) {   // a pixel stopped: the rounds still to come only need entries that reach the rest
+                            int ax, ay, bx, by;
+                            live_box(live, ax, ay, bx, by);
+                            bx0 = x0f + (float)ax; by0 = y0f + (float)ay; bx1 = x0f + (float)bx; by1 = y0f + (float)by;
+                        }
                     }
                 };
                 const int npairs = (int)((nsurv + 1u) >> 1);

@@ -3,7 +3,9 @@
 // A 16x16 tile's list (built from each Gaussian's 3-sigma bounding SQUARE in tile units, reference
 // CR/auxiliary.h:46-56) holds many entries that cannot reach alpha >= 1/255 at any pixel of a given 8x8
 // quadrant.  The reference evaluates them anyway and skips them pixel by pixel (CR/forward.cu:336-347); here
-// the staging lane decides once per (entry, quadrant) and a wave only walks the entries that may matter.
+// the staging lane decides once per (entry, quadrant) and a wave only walks the entries that may matter.  The test
+// rectangle is the bounding box of the pixels that can still be affected (all 64 at first; it shrinks as pixels of the
+// quadrant terminate in the forward pass, and covers only the pixels that consumed that deep in the backward pass).
 // Skipping is invisible in the results as long as it is CONSERVATIVE: an entry is dropped for a quadrant only
 // when  max over the quadrant's pixel centres of power(d) + E  <  log(1/(255*opacity)),  where
 // power(d) = -0.5 (A dx^2 + C dy^2) - B dx dy is concave for a positive-definite conic, its maximum over a
@@ -16,19 +18,20 @@ namespace gsr {
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// May the Gaussian (mean (mx,my), conic (A,B,C), opacity o) reach alpha >= 1/255 at a pixel centre of the 8x8
-// block whose first pixel is (x0,y0)?  false = provably not.
-__device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float B, float C, float o, float x0, float y0)
+// May the Gaussian (mean (mx,my), conic (A,B,C), opacity o) reach alpha >= 1/255 at a pixel centre inside the
+// rectangle [x0, x1] x [y0, y1] (pixel-centre coordinates, inclusive)?  false = provably not.
+__device__ __forceinline__ bool may_touch_rect(float mx, float my, float A, float B, float C, float o, float x0, float y0,
+                                               float x1, float y1)
 {
     if (!(o == o) || !(A == A) || !(B == B) || !(C == C) || !(mx == mx) || !(my == my)) return true;  // NaN: keep
     if (!(o > 0.f)) return false;  // alpha = o*exp(..) <= 0 < 1/255 at every pixel
     if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;  // not provably concave: keep
     const float thr = -__logf(255.0f * o);  // alpha >= 1/255  <=>  power >= thr
-    // d = mean - pixel, pixel centres span [x0, x0+7] x [y0, y0+7]
-    const float dxl = mx - (x0 + 7.f), dxh = mx - x0, dyl = my - (y0 + 7.f), dyh = my - y0;
+    // d = mean - pixel over the rectangle
+    const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
     float m;
     if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) {
-        m = 0.f;  // the mean lies inside the block
+        m = 0.f;  // the mean lies inside the rectangle
     } else {
         m = -3.0e38f;
 #pragma unroll
@@ -44,6 +47,25 @@ __device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float
     const float ax = fmaxf(fabsf(dxl), fabsf(dxh)), ay = fmaxf(fabsf(dyl), fabsf(dyh));
     const float E = 1.0e-5f * (A * ax * ax + C * ay * ay + fabsf(B) * ax * ay) + 1.0e-4f + 1.0e-5f * fabsf(thr);
     return !(m + E < thr);
+}
+
+__device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float B, float C, float o, float x0, float y0)
+{
+    return may_touch_rect(mx, my, A, B, C, o, x0, y0, x0 + 7.f, y0 + 7.f);
+}
+
+// Bounding rectangle, in lane coordinates (x = lane & 7, y = lane >> 3), of the lanes set in a ballot of an 8x8
+// quadrant wave.  Scalar code.  mask must not be 0.
+__device__ __forceinline__ void live_box(uint64_t mask, int& xmin, int& ymin, int& xmax, int& ymax)
+{
+    ymin = (int)__builtin_ctzll(mask) >> 3;
+    ymax = (63 - (int)__builtin_clzll(mask)) >> 3;
+    uint32_t rows = (uint32_t)mask | (uint32_t)(mask >> 32);   // fold the 8 rows onto one byte
+    rows |= rows >> 16;
+    rows |= rows >> 8;
+    rows &= 0xFFu;
+    xmin = (int)__builtin_ctz(rows);
+    xmax = 31 - (int)__builtin_clz(rows);
 }
 
 // 4-bit mask over the quadrants q = (qx | qy<<1) of the 16x16 tile whose first pixel is (tile_px, tile_py).
