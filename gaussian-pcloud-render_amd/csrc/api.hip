@@ -250,12 +250,12 @@ int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, cons
 
 int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* geom, size_t geom_bytes, const void* binning,
                  size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
-                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* grad_rec, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscale, float* dL_drot, gsr_stream_t stream)
 {
     if (int e = check_params(p)) return e;
     if (p->P == 0) return GSR_OK;
-    if (!radii || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+    if (!radii || !dL_dpix || !dL_dmean2D || !grad_rec || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail(GSR_ERR_INVALID, "[gsr] a required backward pointer is NULL");
     if (p->shs && !dL_dsh) return fail(GSR_ERR_INVALID, "[gsr] dL_dsh is NULL");
     if (p->scales && (!dL_dscale || !dL_drot)) return fail(GSR_ERR_INVALID, "[gsr] dL_dscale/dL_drot is NULL");
@@ -274,11 +274,11 @@ int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* g
     }
     {
         ProfScope ps("render_backward", L.stream);
-        if (int e = launch_render_backward(L, *p, g, b.val[res], iv, b.ckpt, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor)) return e;
+        if (int e = launch_render_backward(L, *p, g, b.val[res], iv, b.ckpt, dL_dpix, grad_rec)) return e;
     }
     {
         ProfScope ps("preprocess_backward", L.stream);
-        if (int e = launch_preprocess_backward(L, *p, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+        if (int e = launch_preprocess_backward(L, *p, g, radii, grad_rec, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                                dL_dscale, dL_drot))
             return e;
     }

@@ -191,13 +191,19 @@ int launch_bwd_items(const Launch& L, const ImageView& iv, int T);
 // ckpt: chunk-boundary state for the backward pass (NULL: not recorded, e.g. inference / colour-only re-render)
 int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
                           const ImageView& iv, float* out_color, float4* ckpt);
+// grad_rec: [P][GRAD_REC_WORDS] zero-filled accumulation records, one 64-B line per Gaussian:
+//   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5..7 colour r g b  8 opacity  (9..15 unused)
+// The nine float atomics a (quadrant, entry) issues land in ONE cache line instead of four arrays' worth
+// (scripts/probe/atomic_probe.hip: 4x the atomic throughput).
+constexpr int GRAD_REC_WORDS = 16;
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* dL_dmean2D,
-                           float* dL_dconic, float* dL_dopacity, float* dL_dcolor);
+                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* grad_rec);
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
 // preprocess_bwd.hip
+// reads grad_rec; writes the user-facing dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3] (copies of the record's
+// fields) for every Gaussian besides the geometric gradients
 int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,
-                               const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolor,
+                               const float* grad_rec, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                                float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
 
 }  // namespace gsr

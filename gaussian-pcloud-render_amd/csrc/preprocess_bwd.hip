@@ -32,7 +32,8 @@ struct PreBwdArgs {
     const float *means3D, *shs, *scales, *rotations, *cov3D_precomp, *view, *proj, *campos;
     const int* radii;
     const uint8_t* clamped;
-    const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+    const float* grad_rec;                         // [P][GRAD_REC_WORDS], see common.hpp
+    float *dL_dmean2D, *dL_dopacity, *dL_dcolor;   // user-facing copies of record fields
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 
@@ -117,6 +118,17 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.P) return;
+    // the render-level sums of this Gaussian: one 64-B record (zeros when nothing was accumulated, e.g. invisible)
+    const float4 rec0 = *reinterpret_cast<const float4*>(a.grad_rec + (size_t)idx * GRAD_REC_WORDS);
+    const float4 rec1 = *reinterpret_cast<const float4*>(a.grad_rec + (size_t)idx * GRAD_REC_WORDS + 4);
+    const float rec8 = a.grad_rec[(size_t)idx * GRAD_REC_WORDS + 8];
+    a.dL_dmean2D[3 * (size_t)idx + 0] = rec0.x;
+    a.dL_dmean2D[3 * (size_t)idx + 1] = rec0.y;
+    a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+    a.dL_dcolor[3 * (size_t)idx + 0] = rec1.y;
+    a.dL_dcolor[3 * (size_t)idx + 1] = rec1.z;
+    a.dL_dcolor[3 * (size_t)idx + 2] = rec1.w;
+    a.dL_dopacity[idx] = rec8;
     if (!(a.radii[idx] > 0)) {
         // invisible Gaussian: no gradient.  The per-Gaussian outputs this kernel owns are written for every index, so the
         // caller does not have to clear them first (the atomically accumulated ones and dL_dsh's unused rows it does).
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     }
 
     // ---- conic -> cov2D -> cov3D, and the mean through J (reference CR/backward.cu:144-274)
-    const float gcx = a.dL_dconic[4 * (size_t)idx], gcy = a.dL_dconic[4 * (size_t)idx + 1], gcz = a.dL_dconic[4 * (size_t)idx + 3];
+    const float gcx = rec0.z, gcy = rec0.w, gcz = rec1.x;
     const float h_x = a.focal_x, h_y = a.focal_y;
     const Cov2D c = cov2d_project(mean, h_x, h_y, a.tanfovx, a.tanfovy, cov6, view);
     const V3 t = c.t;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
         const float m_w = 1.0f / (m_hom_w + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float gx = a.dL_dmean2D[3 * (size_t)idx], gy = a.dL_dmean2D[3 * (size_t)idx + 1];
+        const float gx = rec0.x, gy = rec0.y;
         V3 d;
         d.x = (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
         d.y = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     // ---- colour -> SH (+ view-direction term on the mean)
     if (a.shs) {
         const V3 cam = v3(a.campos[0], a.campos[1], a.campos[2]);
-        const V3 dL_dRGB = v3(a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]);
+        const V3 dL_dRGB = v3(rec1.y, rec1.z, rec1.w);
         const V3 d = sh_backward(a.D, mean, cam, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dL_dRGB,
                                  a.dL_dsh + (size_t)idx * a.M * 3);
         dmean = dmean + d;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 }
 
 int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,
-                               const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolor,
+                               const float* grad_rec, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                                float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot)
 {
     PreBwdArgs a;
@@ -297,7 +309,7 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomV
     a.means3D = p.means3D; a.shs = p.shs; a.scales = p.scales; a.rotations = p.rotations;
     a.cov3D_precomp = p.cov3D_precomp; a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
     a.radii = radii; a.clamped = g.clamped;
-    a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dcolor = dL_dcolor;
+    a.grad_rec = grad_rec; a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((p.P + 255) / 256), dim3(256), 0, L.stream, a);
     return check_launch(L, "preprocess_backward");

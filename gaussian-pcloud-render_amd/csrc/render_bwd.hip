@@ -209,10 +209,7 @@ struct RenderBwdArgs {
     const float* final_T;
     const uint32_t* n_contrib;
     const float* dL_dpix;
-    float* dL_dmean2D;   // [P,3]
-    float* dL_dconic;    // [P,4]
-    float* dL_dopacity;  // [P]
-    float* dL_dcolor;    // [P,3]
+    float* grad_rec;     // [P][GRAD_REC_WORDS] accumulation records (common.hpp)
 };
 
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
@@ -269,25 +266,18 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     const float ddelx_dx = (float)(0.5 * a.W);
     const float ddely_dy = (float)(0.5 * a.H);
 
-    // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3,
+    // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3 of the group,
     // component c = i & 7 in {mean2D.x, mean2D.y, conic.x, conic.y, conic.w, colour r, g, b}; odd lanes 1, 17, 33, 49
-    // own the opacity gradient of entries 0..3.  target = base + id * stride.
-    char* tgt_base = nullptr;
-    uint32_t tgt_stride = 0;
-    int tgt_k = 0;
+    // own the opacity gradient (component 8) of entries 0..3.  target = grad_rec[id][c]: the nine atomics of an entry
+    // fall into one 64-B line.
+    int tgt_k = (int)(lane >> 4), tgt_c = 0;
     bool tgt_on = false;
     if ((lane & 1u) == 0) {
-        const uint32_t i = lane >> 1, c = i & 7u;
-        tgt_k = (int)(i >> 3);
+        tgt_c = (int)((lane >> 1) & 7u);
         tgt_on = true;
-        if (c < 2) { tgt_base = (char*)(a.dL_dmean2D + c); tgt_stride = 12; }
-        else if (c < 5) { tgt_base = (char*)(a.dL_dconic + (c == 4 ? 3 : c - 2)); tgt_stride = 16; }
-        else { tgt_base = (char*)(a.dL_dcolor + (c - 5)); tgt_stride = 12; }
     } else if ((lane & 15u) == 1) {
-        tgt_k = (int)(lane >> 4);
+        tgt_c = 8;
         tgt_on = true;
-        tgt_base = (char*)a.dL_dopacity;
-        tgt_stride = 4;
     }
 
     // the staging area starts as zeros, so slots of a partly filled last group always hold finite values (their
@@ -468,7 +458,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const float val = (lane & 1u) ? z : w;
             // this lane's entry id, straight from the id row of the group
             const uint32_t id = __builtin_bit_cast(uint32_t, stage[(quad - 1) * QUAD_WORDS + 36 + tgt_k]);
-            if (tgt_on && val != 0.f) atomicAdd(reinterpret_cast<float*>(tgt_base + (size_t)id * tgt_stride), val);
+            if (tgt_on && val != 0.f) atomicAdd(a.grad_rec + (size_t)id * GRAD_REC_WORDS + tgt_c, val);
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2b), "+v"(id_nn)::"memory");
         c0 = n0; c1 = n1; c2b = n2b;
@@ -479,8 +469,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 }
 
 int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                           float* dL_dopacity, float* dL_dcolor)
+                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* grad_rec)
 {
     RenderBwdArgs a;
     a.ranges = iv.ranges;
@@ -497,10 +486,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView&
     a.final_T = iv.final_T;
     a.n_contrib = iv.n_contrib;
     a.dL_dpix = dL_dpix;
-    a.dL_dmean2D = dL_dmean2D;
-    a.dL_dconic = dL_dconic;
-    a.dL_dopacity = dL_dopacity;
-    a.dL_dcolor = dL_dcolor;
+    a.grad_rec = grad_rec;
     a.num_tiles = a.gridx * gridy;
     // the number of items is only known on the device: a grid of one workgroup quartet per tile (as many wave slots as
     // the chip has several times over) walks the item list with a stride

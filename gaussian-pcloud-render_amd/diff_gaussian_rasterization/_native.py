@@ -198,23 +198,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
     M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0
     z = dict(dtype=torch.float32, device=device)
-    # Atomically accumulated outputs and dL_dsh (unused rows stay zero) are cleared -- as slices of ONE zero-filled
-    # allocation, so the clearing is one fill kernel instead of five; the rest is written for every Gaussian by the
-    # per-Gaussian backward kernel (see include/gsr.h), so clearing them first would only cost bandwidth.
+    # Cleared by the caller (include/gsr.h): the [P,16] accumulation records of the render backward and dL_dsh (unused
+    # rows stay zero) -- slices of ONE zero-filled allocation, so the clearing is one fill kernel.  Everything else is
+    # written for every Gaussian by the per-Gaussian backward kernel.
     has_sr = scales.numel() != 0 and P != 0
-    sizes = (3 * P, 3 * P, 4 * P, P, 3 * M * P)
-    offs, total = [], 0
-    for n in sizes:
-        offs.append(total)
-        total += (n + 63) // 64 * 64          # keep every slice 256-B aligned
-    flat = torch.zeros((total,), **z)
-    dL_dmeans2D = flat[offs[0]:offs[0] + sizes[0]].view(P, 3)
-    dL_dcolors = flat[offs[1]:offs[1] + sizes[1]].view(P, 3)
-    dL_dconic = flat[offs[2]:offs[2] + sizes[2]].view(P, 2, 2)
-    dL_dopacity = flat[offs[3]:offs[3] + sizes[3]].view(P, 1)
-    dL_dsh = flat[offs[4]:offs[4] + sizes[4]].view(P, M, 3)
-    dL_dmeans3D = torch.empty((P, 3), **z) if P != 0 else torch.zeros((P, 3), **z)
-    dL_dcov3D = torch.empty((P, 6), **z) if P != 0 else torch.zeros((P, 6), **z)
+    n_rec = 16 * P
+    flat = torch.zeros((n_rec + 3 * M * P,), **z)
+    grad_rec = flat[:n_rec]
+    dL_dsh = flat[n_rec:].view(P, M, 3)
+    e_or_z = torch.empty if P != 0 else torch.zeros
+    dL_dmeans2D = e_or_z((P, 3), **z)
+    dL_dcolors = e_or_z((P, 3), **z)
+    dL_dopacity = e_or_z((P, 1), **z)
+    dL_dmeans3D = e_or_z((P, 3), **z)
+    dL_dcov3D = e_or_z((P, 6), **z)
     dL_dscales = torch.empty((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
     dL_drotations = torch.empty((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
@@ -228,7 +225,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             radii_c = radii.contiguous()
             _check(lib.gsr_backward(C.byref(p), radii_c.data_ptr(), int(R), geomBuffer.data_ptr(), geomBuffer.numel(),
                                     binningBuffer.data_ptr(), binningBuffer.numel(), imageBuffer.data_ptr(),
-                                    imageBuffer.numel(), dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                                    imageBuffer.numel(), dpix.data_ptr(), dL_dmeans2D.data_ptr(), grad_rec.data_ptr(),
                                     dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
                                     dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
                                     stream))

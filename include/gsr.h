@@ -104,15 +104,17 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
 int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
                         void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
 
-/* Backward.  The reference zero-fills all dL_* outputs (rasterize_points.cu:151-159); here the caller has to zero-fill
- * dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor (accumulated atomically) and dL_dsh (only (D+1)^2 rows are written);
- * dL_dmean3D and dL_dcov3D, and dL_dscale / dL_drot when scales / rotations are given, are written for every Gaussian
- * (zeros for invisible ones) and need no clearing.  With cov3D_precomp, dL_dscale / dL_drot are not touched.
- * shapes: dL_dmean2D[P,3] dL_dconic[P,2,2] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3]
- * dL_dcov3D[P,6] dL_dsh[P,M,3] dL_dscale[P,3] dL_drot[P,4]. */
+/* Backward.  The reference zero-fills all dL_* outputs (rasterize_points.cu:151-159) and accumulates into them with
+ * float atomics.  Here the render-level sums are accumulated in `grad_rec`, [P][16] floats that the CALLER ZERO-FILLS: one
+ * 64-byte record per Gaussian (mean2D.xy, conic.xyw, colour rgb, opacity; the reference's internal dL_dconic tensor lives
+ * in it), so that the nine atomics of a (pixel block, Gaussian) pair fall into one cache line.  Every other output is
+ * written for every Gaussian (zeros for invisible ones) and needs no clearing, except dL_dsh, of which only (D+1)^2 rows
+ * are written (caller zero-fills), and dL_dscale / dL_drot, which are not touched when cov3D_precomp is given.
+ * shapes: dL_dmean2D[P,3] grad_rec[P,16] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3]
+ * dL_dscale[P,3] dL_drot[P,4]. */
 int gsr_backward(const gsr_params* p, const int* radii, int64_t num_rendered, const void* geom, size_t geom_bytes,
                  const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
-                 const float* dL_dpix /* [3,H,W] */, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                 const float* dL_dpix /* [3,H,W] */, float* dL_dmean2D, float* grad_rec, float* dL_dopacity,
                  float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                  float* dL_drot, gsr_stream_t stream);
 
