@@ -33,10 +33,11 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Per-Gaussian packed splat record, 48 B, 16-B aligned: what the render kernels gather per list entry.
-//   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, depth, 0, 0)
-struct __attribute__((aligned(16))) Splat {
-    float4 q0, q1, q2;
+// Per-Gaussian packed splat record: what the render kernels gather per list entry.  Padded to one 64-B cache line, so a
+// gather touches exactly one line (a 48-B record straddles two half of the time) and preprocess writes whole lines.
+//   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, depth, 0, 0)   q3 = padding
+struct __attribute__((aligned(64))) Splat {
+    float4 q0, q1, q2, q3;
 };
 
 // ---- arena views (device pointers carved out of the caller's opaque buffers) -------------------

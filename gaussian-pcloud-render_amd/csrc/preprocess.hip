@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     a.tiles_touched[idx] = tiles;
     a.dkey[idx] = key;
     a.rect[idx] = rect;
-    a.splat[idx] = s;
+    a.splat[idx].q0 = s.q0;   // (q3 is padding: never written, never read)
+    a.splat[idx].q1 = s.q1;
+    a.splat[idx].q2 = s.q2;
     if (a.need_backward) a.clamped[idx] = (uint8_t)cmask;
 }
 
