@@ -20,7 +20,10 @@ constexpr int TILE_PIX = TILE_X * TILE_Y;
 // ---- radix sort geometry (sort.hip) -----------------------------------------------------------
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ITEMS = 16;
+#ifndef GSR_RS_ITEMS
+#define GSR_RS_ITEMS 16
+#endif
+constexpr int RS_ITEMS = GSR_RS_ITEMS;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // keys per workgroup per pass
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
