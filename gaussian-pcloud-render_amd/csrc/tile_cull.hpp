@@ -34,13 +34,16 @@ __device__ __forceinline__ bool may_touch_rect(float mx, float my, float A, floa
         m = 0.f;  // the mean lies inside the rectangle
     } else {
         m = -3.0e38f;
+        // Along an edge the maximiser is -B e / C (or / A), clamped to the edge.  A 1-ulp reciprocal is enough: evaluating
+        // the concave power a relative 1e-7 away from its maximiser lowers the value by ~1e-14 of its terms, far inside E.
+        const float nB_over_C = -B * __builtin_amdgcn_rcpf(C), nB_over_A = -B * __builtin_amdgcn_rcpf(A);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float ex = e ? dxh : dxl;
-            const float yy = clampf(-B * ex / C, dyl, dyh);
+            const float yy = clampf(nB_over_C * ex, dyl, dyh);
             m = fmaxf(m, -0.5f * (A * ex * ex + C * yy * yy) - B * ex * yy);
             const float ey = e ? dyh : dyl;
-            const float xx = clampf(-B * ey / A, dxl, dxh);
+            const float xx = clampf(nB_over_A * ey, dxl, dxh);
             m = fmaxf(m, -0.5f * (A * xx * xx + C * ey * ey) - B * xx * ey);
         }
     }
