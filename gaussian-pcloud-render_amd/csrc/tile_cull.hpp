@@ -23,8 +23,10 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 __device__ __forceinline__ bool may_touch_rect(float mx, float my, float A, float B, float C, float o, float x0, float y0,
                                                float x1, float y1)
 {
-    if (!(o == o) || !(A == A) || !(B == B) || !(C == C) || !(mx == mx) || !(my == my)) return true;  // NaN: keep
-    if (!(o > 0.f)) return false;  // alpha = o*exp(..) <= 0 < 1/255 at every pixel
+    // NaN anywhere must mean "keep".  No explicit test is needed: every comparison below is written so that it is
+    // false for NaN operands and false means keep (NaN opacity: not <= 0, thr = NaN; NaN conic: not provably concave;
+    // NaN mean: E = NaN), and fmaxf drops a NaN candidate without making the bound larger than a real one.
+    if (o <= 0.f) return false;  // alpha = o*exp(..) <= 0 < 1/255 at every pixel
     if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;  // not provably concave: keep
     const float thr = -__logf(255.0f * o);  // alpha >= 1/255  <=>  power >= thr
     // d = mean - pixel over the rectangle
