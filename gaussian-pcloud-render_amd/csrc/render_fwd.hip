@@ -262,24 +262,25 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         last_contributor = cnt1 ? eidx1 : last_contributor;
                         T = T2;
                     } else {
-                        const float al_[2] = {alpha0, alpha1};
-                        const bool cn_[2] = {cnt0, cnt1};
-                        const float cr_[2] = {r.rg.x, r.rg.z}, cg_[2] = {r.rg.y, r.rg.w}, cb_[2] = {r.b.x, r.b.y};
-                        const uint32_t ei_[2] = {eidx0, eidx1};
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const float test_T = T * (1 - al_[k]);
-                            const bool hit = !done && cn_[k];
-                            const bool stop = hit && (test_T < 0.0001f);
-                            const bool blend = hit && !stop;
-                            C01.x += blend ? cr_[k] * al_[k] * T : 0.f;
-                            C01.y += blend ? cg_[k] * al_[k] * T : 0.f;
-                            C2 += blend ? cb_[k] * al_[k] * T : 0.f;
-                            T = blend ? test_T : T;
-                            last_contributor = blend ? ei_[k] : last_contributor;
-                            stop_at = stop ? ei_[k] : stop_at;
-                            done = done || stop;
-                        }
+                        // Some pixel stops inside this pair.  Only the stopping lanes differ from the optimistic update:
+                        // s0 = entry 0 stops the pixel (T*(1-a0) < 1e-4): neither entry is blended; s1 = entry 0 is blended and
+                        // entry 1 stops it.  With those lanes' alphas forced to 0 the same accumulation applies to everybody
+                        // (the blended values are the reference's c*alpha*T and T*(1-alpha), term for term).
+                        const bool s0 = cnt0 && (T1 < 0.0001f);
+                        const bool s1 = !s0 && cnt1 && (T2 < 0.0001f);
+                        const bool b0 = cnt0 && !s0, b1 = cnt1 && !s0 && !s1;
+                        const float be0 = b0 ? alpha0 : 0.f, be1 = b1 ? alpha1 : 0.f;
+                        const float U1 = T * (1 - be0), U2 = U1 * (1 - be1);
+                        const f32x2 rg0 = {r.rg.x, r.rg.y}, rg1 = {r.rg.z, r.rg.w};
+                        C01 += rg0 * be0 * T;
+                        C2 += r.b.x * be0 * T;
+                        C01 += rg1 * be1 * U1;
+                        C2 += r.b.y * be1 * U1;
+                        last_contributor = b0 ? eidx0 : last_contributor;
+                        last_contributor = b1 ? eidx1 : last_contributor;
+                        T = U2;
+                        stop_at = s0 ? eidx0 : (s1 ? eidx1 : stop_at);
+                        done = done || s0 || s1;
                         const uint64_t live = __ballot(!done);
                         all_done = live == 0;
                         if (!all_done) {   // a pixel stopped: the rounds still to come only need entries that reach the rest
