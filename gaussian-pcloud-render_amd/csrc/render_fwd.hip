@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     // keep entries that can reach one of those
     float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 7.f;
 
-    __shared__ __attribute__((aligned(16))) float stage[32 * PAIR_WORDS];
+    __shared__ __attribute__((aligned(16))) float stage[33 * PAIR_WORDS];   // 32 pairs + one that may be read, never used
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 // Pair p+1 is read from LDS while pair p is evaluated.  The loop body is written out twice with the two
                 // register sets swapped, so no register moves are needed to rotate them.
                 auto eval_pair = [&](const PairRec& r) {
+                    __builtin_amdgcn_s_waitcnt(0xC57F);   // lgkmcnt(5): this pair has landed (DS returns in order); the five reads of the next pair stay in flight
                     // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
                     // share packed fp32 instructions (v_pk_*_f32).
                     const uint32_t eidx0 = r.pos.x, eidx1 = r.pos.y;
@@ -290,19 +291,20 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         }
                     }
                 };
-                const int npairs = (int)((nsurv + 1u) >> 1);
+                // The next pair is always read (the staging area has a spare pair, so reading one past the last is harmless)
+                // and the loop ends on the pair count alone: when every pixel is done the count is set to 0.
+                int npairs = (int)((nsurv + 1u) >> 1);
                 int pair = 0;
-                PairRec ra = read_pair(stage, 0), rb;  // rb is always read from LDS before it is evaluated
+                PairRec ra = read_pair(stage, 0), rb;
                 for (;;) {
-                    bool more = pair + 1 < npairs;
-                    if (more) rb = read_pair(stage, pair + 1);
+                    rb = read_pair(stage, pair + 1);
                     eval_pair(ra);
-                    if (!more || all_done) break;
-                    more = pair + 2 < npairs;
-                    if (more) ra = read_pair(stage, pair + 2);
+                    if (all_done) npairs = 0;
+                    if (++pair >= npairs) break;
+                    ra = read_pair(stage, pair + 1);
                     eval_pair(rb);
-                    if (!more || all_done) break;
-                    pair += 2;
+                    if (all_done) npairs = 0;
+                    if (++pair >= npairs) break;
                 }
             }
             retire_prefetch(n0, n1, n2b, id_nn);
