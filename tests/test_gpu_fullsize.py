@@ -156,3 +156,26 @@ def test_fullsize_gradient_matches_directional_finite_difference(gpu_device):
     # cut at 1/255, 0.99 clamp, T < 1e-4 stop, SH clamp at 0), so agreement is asked relative to the sum of |terms|
     scale = float(np.abs(t_op).sum() + np.abs(t_sh).sum())
     assert abs(fd - an) <= 2e-3 * scale, (fd, an, scale)
+
+
+def test_more_than_65536_tiles_uses_32_bit_tile_keys(gpu_device):
+    """4096 x 4112 pixels = 256 x 257 = 65 792 tiles: tile ids no longer fit the 16-bit keys of the usual tile sort, and
+    the tile-id part of the reference's key needs 17 bits (three 8-bit-or-less passes here)."""
+    from pcrender import synth
+    ref = _ref()
+    W, H = 4096, 4112
+    g = synth.random_scene(3000, W, H, seed=31, sh_degree=1, spread=1.6, scale=0.02)
+    s = util.scene_from(g, util.identity_camera(W, H), W, H, bg=(0.1, 0.2, 0.3))
+    r = ref.forward(s)
+    p, _ = run_product(s, gpu_device)
+    assert p["R"] == r["R"] and p["R"] > 10_000
+    assert int(r["keys"].max() >> np.uint64(32)) >= 65536, "scene does not reach a tile id beyond 16 bits"
+    for k in ("radii", "tiles_touched", "vals", "keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(p[k], r[k], err_msg=k)
+    assert p["out_color"].tobytes() == r["out_color"].tobytes()
+    dL = util.seeded_dL(s)
+    _, gr = ref.forward_backward(s, dL)
+    _, gp = run_product(s, gpu_device, dL_dpix=dL)
+    for k in ("dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh"):
+        a, b = gp[k].astype(np.float64), gr[k].astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-30, k
