@@ -12,9 +12,15 @@ rendering whole frames (forward + backward) on its own HIP stream; the tail of o
 the bandwidth-bound stages of the next.  The single-stream rate and the per-stage timings are measured in a second,
 single-stream pass right after the timed region and reported next to the headline value.
 
+`--gpus N` with N > 1 and no torch.distributed.run environment re-launches itself under torch.distributed.run with N ranks
+(one per GPU, RCCL); it refuses loudly when the box has fewer than N GPUs.  The timed region is `--repeats` (default 5)
+blocks of exactly K steps each, every block bracketed by barrier + synchronize; `value` / `ms_per_step` are the MEDIAN block
+(max over ranks per block), all blocks are listed in `ms_per_step_blocks`.
+
 Prints ONE JSON line on rank 0 with the throughput plus
   roofline     -- the dominant kernel's algorithmic bytes / its measured duration (hipEvents on the launch stream)
-  cpu_baseline -- the plain-C oracle (OpenMP, all host cores) timed on one frame of the same workload (rank 0, N=1).
+  cpu_baseline -- the plain-C oracle (OpenMP) on frames of the same workload (rank 0, N=1): 1 warm-up + median of 5 frames on
+                  all host cores, plus a 1-core figure from one frame.
 """
 import argparse
 import json
@@ -71,6 +77,12 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "1")),
+                    help="frames submitted per rasterizer call: 1 = the reference's per-view GaussianRasterizer call; V > 1 = "
+                         "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission")
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the all-core CPU baseline (after 1 warm-up)")
+    ap.add_argument("--no-cpu-1core", action="store_true", help="skip the 1-core CPU figure (about a minute of CPU time)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "4")),
                     help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -79,23 +91,41 @@ def main():
     ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run
+    if args.gpus > 1 and not launched:
+        # self-launch: one process per GPU over RCCL (the driver normally does this itself)
+        n_dev = torch.cuda.device_count()
+        if args.dist_backend == "nccl" and args.device_index < 0 and n_dev < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; RCCL needs one device per rank "
+                             "(use --dist-backend gloo --device-index 0 to exercise the control flow on one GPU)" % (args.gpus, n_dev))
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev_index = local_rank if args.device_index < 0 else args.device_index
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     host_collectives = args.dist_backend == "gloo"
-    if world > 1:
+    use_dist = launched            # a 1-rank launch under torch.distributed.run still goes through RCCL (gather, barrier, max)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if host_collectives:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _native
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _native, rasterize_views
     from pcrender import camera, multiview, synth
 
     W, H = args.width, args.height
@@ -125,9 +155,9 @@ def main():
     scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
     gather_list = [torch.empty((3, H, W), device="cpu" if host_collectives else dev) for _ in range(world)] \
-        if (world > 1 and rank == 0) else None
+        if (use_dist and rank == 0) else None
 
-    do_gather = world > 1 and not args.no_gather
+    do_gather = use_dist and not args.no_gather
 
     def render(i, tslot=0):
         """Forward (+ backward) of global step i on the calling thread's current stream; returns the frame."""
@@ -143,6 +173,26 @@ def main():
             img, _ = rasterizers[v](**L)
         return img
 
+    VPC = max(1, args.views_per_call)
+
+    def render_many(i, n, tslot=0):
+        """Global steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
+        if VPC == 1:
+            return render(i, tslot)[None]
+        L = leafsets[tslot]
+        sts = [settings[((i + k) * world + rank) % n_views] for k in range(n)]
+        if grad:
+            imgs, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], sts, shs=L["shs"], scales=L["scales"],
+                                      rotations=L["rotations"])
+            (imgs * G).sum().backward()
+            for t in L.values():
+                t.grad = None
+            return imgs.detach()
+        with torch.no_grad():
+            imgs, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], sts, shs=L["shs"], scales=L["scales"],
+                                      rotations=L["rotations"])
+        return imgs
+
     def gather(img):
         dist.gather(img.cpu() if host_collectives else img, gather_list=gather_list, dst=0)
 
@@ -153,54 +203,68 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(first, count):
-        """`count` steps from global step `first`: --streams frames in flight (pcrender.multiview.run_frames_pipelined);
-        the frame gather is issued by this thread only, in step order, so every rank enqueues collectives identically."""
-        multiview.run_frames_pipelined(render, first, count, args.streams,
-                                       on_frame=(lambda i, img: gather(img)) if do_gather else None, device=dev)
+    def run_steps(first, count, streams=None):
+        """`count` steps from global step `first`, submitted --views-per-call at a time, --streams submissions in flight
+        (pcrender.multiview.run_frames_pipelined); the frame gather is issued by this thread only, in step order, so every
+        rank enqueues collectives identically."""
+        ch = []
+        i = first
+        while i < first + count:
+            n = min(VPC, first + count - i)
+            ch.append((i, n))
+            i += n
+        multiview.run_frames_pipelined(lambda ci, slot: render_many(ch[ci][0], ch[ci][1], slot), 0, len(ch),
+                                       args.streams if streams is None else streams,
+                                       on_frame=(lambda ci, imgs: [gather(im) for im in imgs]) if do_gather else None, device=dev)
 
     # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
     # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing
     warm = max(args.warmup, 3 * max(1, args.streams))
     for i in range(3):
         step(i)
-    run_steps(0, warm)
+    run_steps(0, max(warm, VPC * max(1, args.streams) * 2))
     fence()
     _native.set_profiling(rank == 0 and args.streams <= 1)
-    t0 = time.perf_counter()
-    run_steps(warm, args.steps)
-    fence()
-    dt = time.perf_counter() - t0
+    block_dt = []
+    nxt = warm
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        run_steps(nxt, args.steps)
+        fence()
+        block_dt.append(time.perf_counter() - t0)
+        nxt += args.steps
     prof = _native.get_profile() if rank == 0 else []
     _native.set_profiling(False)
     kernel_timing = "hipEvents on the launch stream over the timed region"
     single = None
     if rank == 0 and args.streams > 1:
         # with several streams in flight the per-stage events overlap; time the stages in a single-stream pass instead
-        n1 = min(args.steps, 24)
+        n1 = max(min(args.steps, 24), VPC)
         torch.cuda.synchronize()
         _native.set_profiling(True)
         t1 = time.perf_counter()
-        for i in range(n1):
-            render(warm + i)          # no gather here: this pass runs on rank 0 only, a collective would never complete
+        _gather_on, do_gather = do_gather, False     # this pass runs on rank 0 only, a collective would never complete
+        run_steps(warm, n1, streams=1)
+        do_gather = _gather_on
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
         prof = _native.get_profile()
         _native.set_profiling(False)
         single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1}
         kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % n1
-    if world > 1:
-        t = torch.tensor([dt], device="cpu" if host_collectives else dev, dtype=torch.float64)
+    if use_dist:
+        t = torch.tensor(block_dt, device="cpu" if host_collectives else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        block_dt = [float(x) for x in t.tolist()]
+    dt = float(np.median(block_dt))
 
     if rank == 0:
         # ---- workload statistics for the bytes model, averaged over the views rank 0 rendered
-        used = sorted({((warm + i) * world) % n_views for i in range(args.steps)})
+        used = sorted({((warm + i) * world) % n_views for i in range(args.steps * max(1, args.repeats))})
         stats = dict(V=0.0, R=0.0, C_fwd=0.0, C_bwd=0.0)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         with torch.no_grad():
@@ -238,17 +302,18 @@ def main():
         except (OSError, ValueError):
             traffic = None
         if dom is not None:
-            achieved = bytes_per[dom] / (avg_ms[dom] * 1e-3) / 1e9
+            achieved = bytes_per[dom] * VPC / (avg_ms[dom] * 1e-3) / 1e9     # a launch covers VPC views
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes": int(bytes_per[dom]), "avg_ms": round(avg_ms[dom], 4)}
+                        "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(avg_ms[dom], 4),
+                        "views_per_launch": VPC}
             if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
-                rate = valu / (avg_ms[dom] * 1e-3)
+                rate = valu * VPC / (avg_ms[dom] * 1e-3)
                 roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
                                     "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
                                     "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json"}
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
-        frame_gpu_ms = sum(avg_ms.values())
+        frame_gpu_ms = sum(avg_ms.values()) / VPC
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -259,36 +324,50 @@ def main():
                        opacities=g["opacities"], viewmatrix=v0["viewmatrix"].numpy(), projmatrix=v0["projmatrix"].numpy(),
                        campos=v0["campos"].numpy(), shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
             cores = os.cpu_count() or 1
-            t1 = time.perf_counter()
-            if grad:
-                orc.forward_backward(sc, G.cpu().numpy(), nthreads=cores)
-            else:
-                orc.forward(sc, nthreads=cores)
-            cdt = time.perf_counter() - t1
+            Gh = G.cpu().numpy()
+
+            def cpu_frame(nt):
+                t1 = time.perf_counter()
+                if grad:
+                    orc.forward_backward(sc, Gh, nthreads=nt)
+                else:
+                    orc.forward(sc, nthreads=nt)
+                return time.perf_counter() - t1
+
+            cpu_frame(cores)                                              # warm-up (page faults, thread pool)
+            times = sorted(cpu_frame(cores) for _ in range(max(1, args.cpu_frames)))
+            cdt = float(np.median(times))
+            what = "forward+backward" if grad else "forward"
             cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "1 frame (circle view 0) of the same workload, %s, plain-C oracle with OpenMP" %
-                             ("forward+backward" if grad else "forward")}
+                   "sample": "circle view 0 of the same workload, %s, plain-C oracle with OpenMP: 1 warm-up + median of %d frames "
+                             "(min %.3f s, max %.3f s)" % (what, len(times), times[0], times[-1])}
+            if not args.no_cpu_1core:
+                c1 = cpu_frame(1)
+                cpu["one_core"] = {"value": round(1.0 / c1, 5), "unit": "frames/s", "cores": 1,
+                                   "sample": "1 frame of the same view, %s, single thread (no warm-up: %.1f s of CPU work)" % (what, c1)}
 
         out = {
             "metric": "rendered frames/sec at 1080p (fwd+bwd), THuman-800K" if (grad and (W, H) == (1920, 1080)) else
                       "rendered frames/sec %dx%d (%s)" % (W, H, "fwd+bwd" if grad else "fwd"),
-            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "repeats": len(block_dt),
+            "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in block_dt],
             "warmup": args.warmup, "warmup_effective": warm + 3, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d), view-sharded%s" % (
                 args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M,
-                " + RCCL frame gather" if world > 1 and not args.no_gather else ""),
+                " + RCCL frame gather" if do_gather else ""),
                 "points": P, "num_rendered_avg": int(stats["R"]), "visible_avg": int(stats["V"]),
                 "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()}, "kernel_timing": kernel_timing,
+            "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},
             "streams_per_rank": args.streams, "single_stream": single,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
                           "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,18 +1,23 @@
 // api.hip -- the C ABI of include/gsr.h: argument checks, arena carving, kernel sequencing.
 //
 // Host orchestration corresponding to reference CR/rasterizer_impl.cu:198-336 (Rasterizer::forward) and
-// :340-434 (Rasterizer::backward), re-planned for this library's data flow:
+// :340-434 (Rasterizer::backward), re-planned for this library's data flow.  One submission covers a BATCH of V camera
+// views of one cloud (V = 1 for the reference's per-view API); every launch below has the view as a grid dimension.
 //
-//   stage 1   preprocess                      (1 launch)
-//             depth sort of the P Gaussians   (4 passes x 3 launches, u32 key / u32 id)
-//             offsets scan in depth order     (3 launches)  -> num_rendered
-//             8-byte D2H read-back + stream sync            (the reference's cudaMemcpy at :281)
-//   stage 2   pair emission in depth order    (1 launch)
-//             tile sort                       (ceil(bit/8) passes x 3 launches, u32 tile / u32 id)
-//             tile ranges (+memset)           (1 launch)
-//             tile order by list length       (3 tiny launches)
-//             render                          (1 launch)
-//   backward  render backward, per-Gaussian backward (2 launches)
+//   forward   preprocess (+ clears the frame's bookkeeping)      1 launch
+//             depth sort of the P Gaussians                       4 passes x 3 launches, u32 key / u32 id
+//             pair emission in depth order with its own prefix sum  1 launch     -> num_rendered, ON THE DEVICE
+//             tile sort                                           ceil(bit/8) passes x 3 launches, u16|u32 tile / u32 id
+//             tile ranges, tile order by list length              2 launches
+//             render                                              1 launch
+//   backward  work items, render backward, per-Gaussian backward  3 launches
+//
+// No host round trip inside a frame: where the reference blocks on a device->host copy of num_rendered to size its
+// binning buffer (CR/rasterizer_impl.cu:279-285), the binning arena here is carved by CAPACITY (what the caller
+// allocated; the Python layer sizes it from the previous frames of the same configuration), every kernel behind the pair
+// emission takes its element count from device memory, and the 16-byte counter copy is enqueued right after the emission
+// but only waited for once the WHOLE frame has been enqueued.  If a view's count exceeds the capacity the call returns
+// GSR_RETRY with the true counts and the caller repeats the binning half with a larger arena (resume = 1).
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +27,7 @@
 
 #include "common.hpp"
 #include <atomic>
+#include <map>
 #include <mutex>
 
 namespace gsr {
@@ -45,27 +51,31 @@ int check_launch(const Launch& L, const char* what)
     return GSR_OK;
 }
 
-// ---- optional per-step timing (hipEvents on the launch stream, pooled) ---------------------------
+// ---- optional per-step timing (hipEvents on the launch stream) -------------------------------------
+// Records are kept PER STREAM (several host threads may render at once, each on its own stream, and one frame's forward
+// and backward usually come from different host threads -- autograd runs the backward on its own thread -- but on the
+// same stream).  The switch is process wide.
 struct ProfEntry {
     const char* name;
-    int a, b;  // indices into the event pool
+    int a, b;  // indices into the stream's event pool
 };
-// (several host threads may render at once: the tables are guarded, the flag is atomic)
+struct ProfTables {
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<ProfEntry> rec;
+    int event()
+    {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool.push_back(e);
+        }
+        return (int)used++;
+    }
+};
 static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
-static std::vector<hipEvent_t> g_pool;
-static size_t g_pool_used = 0;
-static std::vector<ProfEntry> g_prof;
-
-static int pool_event()
-{
-    if (g_pool_used == g_pool.size()) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        g_pool.push_back(e);
-    }
-    return (int)g_pool_used++;
-}
+static std::map<hipStream_t, ProfTables> g_prof;   // guarded by g_prof_mu
 
 struct ProfScope {
     hipStream_t s;
@@ -78,9 +88,10 @@ struct ProfScope {
         hipEvent_t ea;
         {
             std::lock_guard<std::mutex> lk(g_prof_mu);
-            e.a = pool_event();
-            e.b = pool_event();
-            ea = g_pool[e.a];
+            ProfTables& t = g_prof[s];
+            e.a = t.event();
+            e.b = t.event();
+            ea = t.pool[e.a];
         }
         (void)hipEventRecord(ea, s);
     }
@@ -88,15 +99,37 @@ struct ProfScope {
     {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        (void)hipEventRecord(g_pool[e.b], s);
-        g_prof.push_back(e);
+        ProfTables& t = g_prof[s];
+        (void)hipEventRecord(t.pool[e.b], s);
+        t.rec.push_back(e);
     }
 };
 
-static int check_params(const gsr_params* p)
+// ---- per-thread pinned landing zone for the counter read-back ------------------------------------------
+constexpr int MAX_VIEWS = 256;
+struct HostLanding {
+    uint64_t* pinned = nullptr;   // [MAX_VIEWS][2]: num_rendered, trap flag
+    hipEvent_t ev = nullptr;
+    int ensure()
+    {
+        if (pinned) return GSR_OK;
+        if (hipHostMalloc((void**)&pinned, MAX_VIEWS * 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            pinned = nullptr;
+            return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
+        }
+        return GSR_OK;
+    }
+};
+static thread_local HostLanding t_land;
+
+static int tile_count(const gsr_params* p) { return ((p->W + TILE_X - 1) / TILE_X) * ((p->H + TILE_Y - 1) / TILE_Y); }
+
+static int check_params(const gsr_params* p, int V = 1)
 {
     if (!p) return fail(GSR_ERR_INVALID, "[gsr] params is NULL");
     if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(GSR_ERR_INVALID, "[gsr] bad sizes P=%d W=%d H=%d", p->P, p->W, p->H);
+    if (V < 1 || V > MAX_VIEWS) return fail(GSR_ERR_INVALID, "[gsr] view count %d outside 1..%d", V, MAX_VIEWS);
     if (p->P == 0) return GSR_OK;
     if (!p->means3D || !p->opacities || !p->bg || !p->viewmatrix || !p->projmatrix || !p->campos)
         return fail(GSR_ERR_INVALID, "[gsr] a required input pointer is NULL");
@@ -109,15 +142,147 @@ static int check_params(const gsr_params* p)
         if (p->D < 0 || p->D > 3) return fail(GSR_ERR_INVALID, "[gsr] SH degree %d outside 0..3", p->D);
         if ((p->D + 1) * (p->D + 1) > p->M) return fail(GSR_ERR_INVALID, "[gsr] SH degree %d needs %d coefficients, M=%d", p->D, (p->D + 1) * (p->D + 1), p->M);
     }
-    const int gx = (p->W + TILE_X - 1) / TILE_X, gy = (p->H + TILE_Y - 1) / TILE_Y;
+    const int64_t gx = (p->W + TILE_X - 1) / TILE_X, gy = (p->H + TILE_Y - 1) / TILE_Y;
     if (gx > 65535 || gy > 65535) return fail(GSR_ERR_INVALID, "[gsr] image too large for 16-bit tile coordinates");
+    // backward work items carry the tile in BWD_TILE_BITS bits, and the render grids hold 4 workgroups per tile and view
+    if (gx * gy > (1ll << BWD_TILE_BITS) || (gx * gy / 8 + 1) * 32 * V > 0x7FFFFFFFll)
+        return fail(GSR_ERR_INVALID, "[gsr] %lld tiles x %d views: too many for one launch", (long long)(gx * gy), V);
     return GSR_OK;
 }
 
-static int tile_count(const gsr_params* p) { return ((p->W + TILE_X - 1) / TILE_X) * ((p->H + TILE_Y - 1) / TILE_Y); }
-
 // how many u32 tile-key bits the tile sort covers: the reference's 32+bit minus the 32 depth bits
 static int tile_bits(int T) { return (int)higher_msb((uint32_t)T); }
+// which of the two ping-pong buffers holds the sorted lists (depends on the pass count only)
+static int sorted_buffer(int T) { return ((tile_bits(T) + RADIX_BITS - 1) / RADIX_BITS) & 1; }
+
+static inline void* align256(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
+
+// Carve the caller's three allocations into V per-view arenas.  binning may be NULL (count-only forward).
+static int make_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
+                      size_t binning_bytes, Batch& B)
+{
+    B.V = V;
+    const size_t G = geom_view(nullptr, p->P).bytes, I = image_view(nullptr, p->W, p->H).bytes;
+    if (!geom || geom_bytes < (size_t)V * G + 256)
+        return fail(GSR_ERR_CAPACITY, "[gsr] geom arena too small (%zu < %zu)", geom_bytes, (size_t)V * G + 256);
+    if (!image || image_bytes < (size_t)V * I + 256)
+        return fail(GSR_ERR_CAPACITY, "[gsr] image arena too small (%zu < %zu)", image_bytes, (size_t)V * I + 256);
+    B.g = geom_view(align256(geom), p->P);
+    B.g_stride = G;
+    B.iv = image_view(align256(image), p->W, p->H);
+    B.iv_stride = I;
+    if (binning) {
+        if (binning_bytes < 256 + 256 * (size_t)V) return fail(GSR_ERR_CAPACITY, "[gsr] binning arena too small");
+        const size_t per_view = ((binning_bytes - 256) / (size_t)V) / 256 * 256;
+        const int64_t cap = bin_capacity_from_bytes(per_view);
+        if (cap < 1) return fail(GSR_ERR_CAPACITY, "[gsr] binning arena too small (%zu bytes for %d views)", binning_bytes, V);
+        B.b = bin_view(align256(binning), cap > 0xFFFFFFFFll ? 0xFFFFFFFFll : cap);
+        B.b_stride = per_view;
+    } else {
+        B.b = bin_view(nullptr, 1);
+        B.b.cap = 0;
+        B.b_stride = 0;
+    }
+    return GSR_OK;
+}
+
+static int memset_views(hipStream_t s, void* base, size_t stride, size_t bytes, int V)
+{
+    if (bytes == 0) return GSR_OK;
+    hipError_t e = V == 1 ? hipMemsetAsync(base, 0, bytes, s) : hipMemset2DAsync(base, stride, 0, bytes, (size_t)V, s);
+    return e == hipSuccess ? GSR_OK : fail(GSR_ERR_HIP, "[gsr] memset failed: %s", hipGetErrorString(e));
+}
+
+// The whole forward for a batch.  mode 0: everything; 1 (resume): from the pair emission on, after a GSR_RETRY or a
+// count-only call; 2 (count only): geometry + pair counting, no binning arena.
+static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
+                        size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int mode, hipStream_t stream)
+{
+    if (int e = check_params(p, V)) return e;
+    if (!num_rendered) return fail(GSR_ERR_INVALID, "[gsr] num_rendered is NULL");
+    for (int v = 0; v < V; v++) num_rendered[v] = 0;
+    if (p->P == 0) return GSR_OK;  // reference rasterize_points.cu:81: nothing runs, image stays zero
+    if (mode != 1 && !radii) return fail(GSR_ERR_INVALID, "[gsr] radii is NULL");
+    if (mode != 2 && !out_color) return fail(GSR_ERR_INVALID, "[gsr] out_color is NULL");
+    if (mode != 2 && !binning) return fail(GSR_ERR_INVALID, "[gsr] binning arena is NULL");
+    Batch B;
+    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, mode == 2 ? nullptr : binning, binning_bytes, B)) return e;
+    if (int e = t_land.ensure()) return e;
+    const Launch L{stream, p->debug};
+    const int T = tile_count(p);
+    const int gridx = (p->W + TILE_X - 1) / TILE_X;
+    const bool key16 = tile_keys16(T);
+
+    if (mode == 1) {
+        // the first attempt consumed the frame's bookkeeping: clear it again (k_preprocess did it the first time)
+        if (int e = memset_views(L.stream, B.g.zero_begin, B.g_stride, B.g.zero_bytes, V)) return e;
+        if (int e = memset_views(L.stream, B.iv.zero_begin, B.iv_stride, B.iv.zero_bytes, V)) return e;
+    } else {
+        if (p->prefiltered)   // the trap word is only looked at for prefiltered calls
+            if (int e = memset_views(L.stream, B.g.counters, B.g_stride, 8 * sizeof(uint64_t), V)) return e;
+        {
+            ProfScope ps("preprocess", L.stream);
+            if (int e = launch_preprocess(L, *p, B, radii)) return e;
+        }
+        {
+            ProfScope ps("depth_sort", L.stream);
+            SortJob job{{B.g.dkey[0], B.g.dkey[1]}, {B.g.dval[0], B.g.dval[1]}, B.g.hist, B.g.totals, B.g_stride, nullptr, 0, p->P, V};
+            int res = 0;
+            if (int e = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 32, &res)) return e;
+            // 4 passes: the ids in depth order are back in buffer 0
+        }
+    }
+    {
+        ProfScope ps("duplicate", L.stream);
+        if (int e = launch_duplicate(L, p->P, B, gridx, key16)) return e;
+    }
+    // counters of every view -> pinned host memory; waited for only after the rest of the frame has been enqueued
+    {
+        hipError_t e = V == 1 ? hipMemcpyAsync(t_land.pinned, B.g.counters, 16, hipMemcpyDeviceToHost, L.stream)
+                              : hipMemcpy2DAsync(t_land.pinned, 16, B.g.counters, B.g_stride, 16, (size_t)V, hipMemcpyDeviceToHost, L.stream);
+        if (e == hipSuccess) e = hipEventRecord(t_land.ev, L.stream);
+        if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
+    }
+    if (mode != 2) {
+        const int res = sorted_buffer(T);
+        {
+            ProfScope ps("tile_sort", L.stream);
+            SortJob job{{B.b.key[0], B.b.key[1]}, {B.b.val[0], B.b.val[1]}, B.b.hist, B.b.totals, B.b_stride,
+                        B.g.counters + CNT_NUM_RENDERED, B.g_stride, B.b.cap, V};
+            int r2 = 0;
+            if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
+        }
+        {
+            ProfScope ps("tile_ranges", L.stream);
+            if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
+            if (int e = launch_tile_order(L, B, T)) return e;
+        }
+        {
+            ProfScope ps("render_forward", L.stream);
+            if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0)) return e;
+        }
+    }
+    if (hipEventSynchronize(t_land.ev) != hipSuccess)
+        return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
+    bool retry = false;
+    for (int v = 0; v < V; v++) {
+        const uint64_t R = t_land.pinned[2 * v];
+        if (p->prefiltered && t_land.pinned[2 * v + 1])
+            return fail(GSR_ERR_TRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        // the reference keeps num_rendered in an int (CR/rasterizer_impl.cu:280); beyond that its arena sizes wrap
+        if (R > 0x7FFFFFFFull)
+            return fail(GSR_ERR_CAPACITY, "[gsr] num_rendered = %llu tile pairs does not fit the reference's int (scales too large?)",
+                        (unsigned long long)R);
+        num_rendered[v] = (int64_t)R;
+        if (mode != 2 && (int64_t)R > B.b.cap) retry = true;
+    }
+    if (retry) {
+        fail(GSR_RETRY, "[gsr] binning arena holds %lld pairs per view, the frame needs more (see num_rendered): repeat with resume = 1",
+             (long long)B.b.cap);
+        return GSR_RETRY;
+    }
+    return GSR_OK;
+}
 
 }  // namespace gsr
 
@@ -129,160 +294,105 @@ size_t gsr_geom_bytes(int P) { return geom_view(nullptr, P).bytes + 256; }
 size_t gsr_image_bytes(int W, int H) { return image_view(nullptr, W, H).bytes + 256; }
 size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, R).bytes + 256; }
 
-static inline void* align256(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
+int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
+                      size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume, gsr_stream_t stream)
+{
+    return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
+                        resume ? 1 : 0, (hipStream_t)stream);
+}
 
 int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void* image, size_t image_bytes, int* radii,
                        int64_t* num_rendered_out, gsr_stream_t stream)
 {
-    if (int e = check_params(p)) return e;
     if (!num_rendered_out) return fail(GSR_ERR_INVALID, "[gsr] num_rendered_out is NULL");
-    *num_rendered_out = 0;
-    if (p->P == 0) return GSR_OK;  // reference rasterize_points.cu:81: nothing runs, image stays zero
-    if (!geom || geom_bytes < gsr_geom_bytes(p->P)) return fail(GSR_ERR_CAPACITY, "[gsr] geom arena too small (%zu < %zu)", geom_bytes, gsr_geom_bytes(p->P));
-    if (!image || image_bytes < gsr_image_bytes(p->W, p->H)) return fail(GSR_ERR_CAPACITY, "[gsr] image arena too small");
-    if (!radii) return fail(GSR_ERR_INVALID, "[gsr] radii is NULL");
-    const Launch L{(hipStream_t)stream, p->debug};
-    const GeomView g = geom_view(align256(geom), p->P);
-
-    if (hipMemsetAsync(g.counters, 0, 8 * sizeof(uint64_t), L.stream) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] memset failed");
-    {
-        ProfScope ps("preprocess", L.stream);
-        if (int e = launch_preprocess(L, *p, g, radii)) return e;
-    }
-    int res = 0;
-    {
-        ProfScope ps("depth_sort", L.stream);
-        uint32_t* key[2] = {g.dkey[0], g.dkey[1]};
-        uint32_t* val[2] = {g.dval[0], g.dval[1]};
-        if (int e = launch_radix_sort_pairs(L, p->P, key, val, /*iota_vals=*/true, 32, g.hist, g.totals, &res)) return e;
-    }
-    // 4 passes: the ids in depth order are back in buffer 0
-    {
-        ProfScope ps("offsets_scan", L.stream);
-        if (int e = launch_offsets_scan(L, p->P, g.dval[res], g.tiles_touched, g.dup_offset, g.scan_tmp, g.counters)) return e;
-    }
-    uint64_t host[2] = {0, 0};
-    if (hipMemcpyAsync(host, g.counters, sizeof(host), hipMemcpyDeviceToHost, L.stream) != hipSuccess ||
-        hipStreamSynchronize(L.stream) != hipSuccess)
-        return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
-    if (host[1]) return fail(GSR_ERR_TRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    // the reference keeps num_rendered in an int (CR/rasterizer_impl.cu:280); beyond that its arena sizes wrap
-    if (host[0] > 0x7FFFFFFFull)
-        return fail(GSR_ERR_CAPACITY, "[gsr] num_rendered = %llu tile pairs does not fit the reference's int (scales too large?)",
-                    (unsigned long long)host[0]);
-    *num_rendered_out = (int64_t)host[0];
-    return GSR_OK;
+    return forward_impl(p, 1, geom, geom_bytes, image, image_bytes, nullptr, 0, radii, nullptr, num_rendered_out, 2, (hipStream_t)stream);
 }
 
 int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
                        size_t image_bytes, int64_t R, float* out_color, gsr_stream_t stream)
 {
-    if (int e = check_params(p)) return e;
-    if (p->P == 0) return GSR_OK;
-    if (!out_color) return fail(GSR_ERR_INVALID, "[gsr] out_color is NULL");
-    if (R < 0 || R > 0xFFFFFFFFll) return fail(GSR_ERR_INVALID, "[gsr] num_rendered out of range");
-    if (!geom || geom_bytes < gsr_geom_bytes(p->P)) return fail(GSR_ERR_CAPACITY, "[gsr] geom arena too small");
-    if (!image || image_bytes < gsr_image_bytes(p->W, p->H)) return fail(GSR_ERR_CAPACITY, "[gsr] image arena too small");
-    if (!binning || binning_bytes < gsr_binning_bytes(R)) return fail(GSR_ERR_CAPACITY, "[gsr] binning arena too small (%zu < %zu)", binning_bytes, gsr_binning_bytes(R));
-    const Launch L{(hipStream_t)stream, p->debug};
-    const GeomView g = geom_view(align256(geom), p->P);
-    const BinView b = bin_view(align256(binning), R);
-    const ImageView iv = image_view(align256(image), p->W, p->H);
-    const int T = tile_count(p);
-    const int gridx = (p->W + TILE_X - 1) / TILE_X;
-
-    int res = 0;
-    if (R > 0) {
-        {
-            ProfScope ps("duplicate", L.stream);
-            if (int e = launch_duplicate(L, p->P, g, g.dval[0], gridx, b.key[0], b.val[0], tile_keys16(T))) return e;
-        }
-        {
-            ProfScope ps("tile_sort", L.stream);
-            uint32_t* key[2] = {b.key[0], b.key[1]};
-            uint32_t* val[2] = {b.val[0], b.val[1]};
-            if (int e = launch_radix_sort_pairs(L, R, key, val, false, tile_bits(T), b.hist, b.totals, &res, tile_keys16(T))) return e;
-        }
-    }
-    {
-        ProfScope ps("tile_ranges", L.stream);
-        if (int e = launch_tile_ranges(L, R, b.key[res], iv.ranges, T, tile_keys16(T))) return e;
-        if (int e = launch_tile_order(L, iv, T)) return e;
-    }
-    {
-        ProfScope ps("render_forward", L.stream);
-        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color, p->need_backward ? b.ckpt : nullptr)) return e;
-    }
-    return GSR_OK;
+    if (R < 0 || R > 0x7FFFFFFFll) return fail(GSR_ERR_INVALID, "[gsr] num_rendered out of range");
+    if (p && p->P > 0 && (!binning || binning_bytes < gsr_binning_bytes(R)))
+        return fail(GSR_ERR_CAPACITY, "[gsr] binning arena too small (%zu < %zu)", binning_bytes, gsr_binning_bytes(R));
+    int64_t got = 0;
+    const int rc = forward_impl(p, 1, geom, geom_bytes, image, image_bytes, binning, binning_bytes, nullptr, out_color, &got, 1,
+                                (hipStream_t)stream);
+    if (rc == GSR_OK && p && p->P > 0 && got != R) return fail(GSR_ERR_INVALID, "[gsr] stage 2 found %lld pairs, stage 1 reported %lld", (long long)got, (long long)R);
+    return rc;
 }
 
-// Colour-only re-render on the geometry / lists of a finished forward (same P, view, image size).
-int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes, void* image,
-                        size_t image_bytes, int64_t R, float* out_color, gsr_stream_t stream)
+// Colour-only re-render on the geometry / lists of a finished forward (same P, views, image size).
+int gsr_forward_recolor(const gsr_params* p, int V, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes, void* image,
+                        size_t image_bytes, float* out_color, gsr_stream_t stream)
 {
     if (!p) return fail(GSR_ERR_INVALID, "[gsr] params is NULL");
+    if (V < 1 || V > MAX_VIEWS) return fail(GSR_ERR_INVALID, "[gsr] view count %d outside 1..%d", V, MAX_VIEWS);
     if (p->P <= 0) return GSR_OK;
     if ((p->shs == nullptr) == (p->colors_precomp == nullptr))
         return fail(GSR_ERR_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
     if (p->shs && (!p->means3D || !p->campos || p->D < 0 || p->D > 3 || (p->D + 1) * (p->D + 1) > p->M))
         return fail(GSR_ERR_INVALID, "[gsr] recolor: bad SH arguments");
-    if (!out_color || !p->bg) return fail(GSR_ERR_INVALID, "[gsr] recolor: NULL pointer");
-    if (R < 0 || R > 0x7FFFFFFFll) return fail(GSR_ERR_INVALID, "[gsr] num_rendered out of range");
-    if (!geom || geom_bytes < gsr_geom_bytes(p->P) || !image || image_bytes < gsr_image_bytes(p->W, p->H) || !binning ||
-        binning_bytes < gsr_binning_bytes(R))
-        return fail(GSR_ERR_CAPACITY, "[gsr] an arena is too small for recolor");
+    if (!out_color || !p->bg || !binning) return fail(GSR_ERR_INVALID, "[gsr] recolor: NULL pointer");
+    Batch B;
+    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, const_cast<void*>(binning), binning_bytes, B)) return e;
     const Launch L{(hipStream_t)stream, p->debug};
-    const GeomView g = geom_view(align256(geom), p->P);
-    const BinView b = bin_view(align256(const_cast<void*>(binning)), R);
-    const ImageView iv = image_view(align256(image), p->W, p->H);
-    const int passes = (tile_bits(tile_count(p)) + RADIX_BITS - 1) / RADIX_BITS;
-    const int res = R > 0 ? (passes & 1) : 0;
+    const int res = sorted_buffer(tile_count(p));
     {
         ProfScope ps("recolor", L.stream);
-        if (int e = launch_recolor(L, *p, g)) return e;
+        if (int e = launch_recolor(L, *p, B)) return e;
+        // the render accumulates the consumed-entry counts from zero
+        if (int e = memset_views(L.stream, B.iv.tile_need, B.iv_stride, (size_t)tile_count(p) * sizeof(uint32_t), V)) return e;
     }
     {
         ProfScope ps("render_forward", L.stream);
-        if (int e = launch_render_forward(L, *p, g, b.val[res], iv, out_color, nullptr)) return e;
+        if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, false)) return e;
+    }
+    return GSR_OK;
+}
+
+int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void* geom, size_t geom_bytes, const void* binning,
+                       size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
+                       float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                       float* dL_drot, gsr_stream_t stream)
+{
+    if (int e = check_params(p, V)) return e;
+    if (p->P == 0) return GSR_OK;
+    if (!radii || !dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail(GSR_ERR_INVALID, "[gsr] a required backward pointer is NULL");
+    if (p->shs && !dL_dsh) return fail(GSR_ERR_INVALID, "[gsr] dL_dsh is NULL");
+    if (p->scales && (!dL_dscale || !dL_drot)) return fail(GSR_ERR_INVALID, "[gsr] dL_dscale/dL_drot is NULL");
+    if (!binning) return fail(GSR_ERR_INVALID, "[gsr] binning arena is NULL");
+    Batch B;
+    if (int e = make_batch(p, V, const_cast<void*>(geom), geom_bytes, const_cast<void*>(image), image_bytes,
+                           const_cast<void*>(binning), binning_bytes, B))
+        return e;
+    const Launch L{(hipStream_t)stream, p->debug};
+    const int res = sorted_buffer(tile_count(p));
+    {
+        ProfScope ps("bwd_items", L.stream);
+        if (int e = launch_bwd_items(L, B, tile_count(p))) return e;
+    }
+    {
+        ProfScope ps("render_backward", L.stream);
+        if (int e = launch_render_backward(L, *p, B, B.b.val[res], dL_dpix)) return e;
+    }
+    {
+        ProfScope ps("preprocess_backward", L.stream);
+        if (int e = launch_preprocess_backward(L, *p, B, radii, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                               dL_dscale, dL_drot))
+            return e;
     }
     return GSR_OK;
 }
 
 int gsr_backward(const gsr_params* p, const int* radii, int64_t R, const void* geom, size_t geom_bytes, const void* binning,
                  size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
-                 float* grad_rec, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscale, float* dL_drot, gsr_stream_t stream)
 {
-    if (int e = check_params(p)) return e;
-    if (p->P == 0) return GSR_OK;
-    if (!radii || !dL_dpix || !dL_dmean2D || !grad_rec || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
-        return fail(GSR_ERR_INVALID, "[gsr] a required backward pointer is NULL");
-    if (p->shs && !dL_dsh) return fail(GSR_ERR_INVALID, "[gsr] dL_dsh is NULL");
-    if (p->scales && (!dL_dscale || !dL_drot)) return fail(GSR_ERR_INVALID, "[gsr] dL_dscale/dL_drot is NULL");
-    if (!geom || geom_bytes < gsr_geom_bytes(p->P) || !image || image_bytes < gsr_image_bytes(p->W, p->H) || !binning ||
-        binning_bytes < gsr_binning_bytes(R))
-        return fail(GSR_ERR_CAPACITY, "[gsr] an arena is too small for backward");
-    const Launch L{(hipStream_t)stream, p->debug};
-    const GeomView g = geom_view(align256(const_cast<void*>(geom)), p->P);
-    const BinView b = bin_view(align256(const_cast<void*>(binning)), R);
-    const ImageView iv = image_view(align256(const_cast<void*>(image)), p->W, p->H);
-    const int passes = (tile_bits(tile_count(p)) + RADIX_BITS - 1) / RADIX_BITS;
-    const int res = R > 0 ? (passes & 1) : 0;
-    {
-        ProfScope ps("bwd_items", L.stream);
-        if (int e = launch_bwd_items(L, iv, tile_count(p))) return e;
-    }
-    {
-        ProfScope ps("render_backward", L.stream);
-        if (int e = launch_render_backward(L, *p, g, b.val[res], iv, b.ckpt, dL_dpix, grad_rec)) return e;
-    }
-    {
-        ProfScope ps("preprocess_backward", L.stream);
-        if (int e = launch_preprocess_backward(L, *p, g, radii, grad_rec, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                               dL_dscale, dL_drot))
-            return e;
-    }
-    return GSR_OK;
+    (void)R;   // the lists' extent lives in the arenas; kept for symmetry with the reference's backward(P, D, M, R, ...)
+    return gsr_backward_batch(p, 1, radii, geom, geom_bytes, binning, binning_bytes, image, image_bytes, dL_dpix, dL_dmean2D,
+                              dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream);
 }
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
@@ -324,18 +434,19 @@ __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const
 }
 }  // namespace
 
-int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, const void* image, int64_t R, void* dst,
-              size_t dst_bytes, gsr_stream_t stream)
+int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, size_t binning_bytes, const void* image,
+              int64_t R, void* dst, size_t dst_bytes, gsr_stream_t stream)
 {
     if (!p || !dst) return fail(GSR_ERR_INVALID, "[gsr] query: NULL");
     hipStream_t s = (hipStream_t)stream;
     const int P = p->P, T = tile_count(p);
     const int64_t N = (int64_t)p->W * p->H;
     const GeomView g = geom_view(align256(const_cast<void*>(geom)), P);
-    const BinView b = bin_view(align256(const_cast<void*>(binning)), R);
+    const int64_t cap = binning ? bin_capacity_from_bytes(((binning_bytes - 256)) / 256 * 256) : 0;
+    if (binning && R > cap) return fail(GSR_ERR_CAPACITY, "[gsr] query: arena holds %lld pairs, R = %lld", (long long)cap, (long long)R);
+    const BinView b = bin_view(align256(const_cast<void*>(binning)), cap > 0 ? cap : 1);
     const ImageView iv = image_view(align256(const_cast<void*>(image)), p->W, p->H);
-    const int passes = (tile_bits(T) + RADIX_BITS - 1) / RADIX_BITS;
-    const int res = R > 0 ? (passes & 1) : 0;
+    const int res = sorted_buffer(T);
     int64_t n = 0;
     size_t bytes = 0;
     const void* src = nullptr;
@@ -397,7 +508,8 @@ int gsr_selftest(gsr_stream_t stream)
     uint32_t* val[2] = {v0, v1};
     int res = 0;
     const Launch L{s, 1};
-    int rc = launch_radix_sort_pairs(L, n, key, val, /*iota_vals=*/true, 12, hist, tot, &res);
+    const SortJob job{{k0, k1}, {v0, v1}, hist, tot, 0, nullptr, 0, n, 1};
+    int rc = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 12, &res);
     std::vector<uint32_t> gk(n), gv(n);
     if (rc == 0) {
         (void)hipMemcpyAsync(gk.data(), key[res], n * 4, hipMemcpyDeviceToHost, s);
@@ -415,29 +527,31 @@ void gsr_set_profiling(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
-    g_prof.clear();
-    g_pool_used = 0;
+    for (auto& kv : g_prof) { kv.second.rec.clear(); kv.second.used = 0; }
 }
 
 int gsr_get_profile(const char** names, float* ms, int cap)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
-    for (auto& e : g_prof) {
-        if (n >= cap) break;
-        (void)hipEventSynchronize(g_pool[e.b]);
-        float t = 0;
-        (void)hipEventElapsedTime(&t, g_pool[e.a], g_pool[e.b]);
-        names[n] = e.name;
-        ms[n] = t;
-        n++;
+    for (auto& kv : g_prof) {
+        ProfTables& t = kv.second;
+        for (auto& e : t.rec) {
+            if (n >= cap) break;
+            (void)hipEventSynchronize(t.pool[e.b]);
+            float d = 0;
+            (void)hipEventElapsedTime(&d, t.pool[e.a], t.pool[e.b]);
+            names[n] = e.name;
+            ms[n] = d;
+            n++;
+        }
+        t.rec.clear();
+        t.used = 0;
     }
-    g_prof.clear();
-    g_pool_used = 0;
     return n;
 }
 
 const char* gsr_last_error(void) { return gsr::g_err; }
-const char* gsr_version(void) { return "gsr-hip 0.1 (gfx950)"; }
+const char* gsr_version(void) { return "gsr-hip 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -1,116 +1,210 @@
-// binning.hip -- (tile, Gaussian) pair emission, per-tile list ranges, render launch order.
+// binning.hip -- (tile, Gaussian) pair emission with its own prefix sum, per-tile list ranges, render launch order.
 //
 // Pair emission follows reference CR/rasterizer_impl.cu:70-111 (duplicateWithKeys): every visible
 // Gaussian emits one pair per tile of its rectangle, rows outer / columns inner.  Differences in
 // structure (results identical after the sort, see sort.hip):
-//   - Gaussians are visited in depth order, the key is just the tile id (u32);
+//   - Gaussians are visited in depth order, the key is just the tile id (u32 / u16);
+//   - the prefix sum of the touched-tile counts (the reference's cub::DeviceScan::InclusiveSum, :277) is done by the
+//     emission kernel itself: a workgroup publishes the pair count of its 256 Gaussians and adds up the counts its
+//     predecessors published (they are dispatched earlier, so they are running or done), which removes the scan
+//     launches and the host read-back between them and the emission: num_rendered stays on the device;
 //   - emission is wave-cooperative: a wave owns 64 consecutive Gaussians, and its lanes write the
 //     wave's whole contiguous output range 64 slots at a time (coalesced 4-B stores) instead of one
-//     thread writing a 10..40-slot run on its own.
+//     thread writing a 10..40-slot run on its own;
+//   - pairs beyond the binning arena's capacity are counted but not written (the host retries with a larger arena).
 // Tile ranges follow reference CR/rasterizer_impl.cu:116-138 (identifyTileRanges) + the memset at :310.
 #include "common.hpp"
 
 namespace gsr {
 
+__device__ __forceinline__ uint64_t agent_load(const uint64_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_store(uint64_t* p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct DupArgs {
+    int P;
+    uint32_t gridx;
+    const uint32_t* order;           // ids in depth order
+    const uint32_t* tiles_touched;
+    const uint2* rect;
+    uint64_t* dup_status;            // [nblk] zeroed before the launch; pair count + 1 once a workgroup has published
+    uint64_t* counters;
+    size_t g_stride;
+    void* keys;                      // NULL: count only
+    uint32_t* vals;
+    size_t b_stride;
+    int64_t cap;
+};
+
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_duplicate(int P, const uint32_t* __restrict__ order,
-                                                   const uint32_t* __restrict__ dup_offset,
-                                                   const uint32_t* __restrict__ tiles_touched,
-                                                   const uint2* __restrict__ rect, uint32_t gridx,
-                                                   KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
+__global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
 {
     __shared__ uint32_t s_off[4][64];
     __shared__ uint32_t s_id[4][64];
     __shared__ uint2 s_rect[4][64];
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_base;
+    const uint32_t view = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 256 + threadIdx.x;  // position in depth order
+    const int slot = blockIdx.x * DUP_THREADS + threadIdx.x;  // position in depth order
+    const uint32_t* order = at_view(a.order, a.g_stride, view);
+    const uint32_t* tiles_touched = at_view(a.tiles_touched, a.g_stride, view);
+    const uint2* rect = at_view(a.rect, a.g_stride, view);
+    uint64_t* status = at_view(a.dup_status, a.g_stride, view);
 
-    uint32_t off = 0, cnt = 0, id = 0;
+    uint32_t cnt = 0, id = 0;
     uint2 rc = make_uint2(0, 0);
-    if (slot < P) {
+    if (slot < a.P) {
         id = order[slot];
-        off = dup_offset[slot];
         cnt = tiles_touched[id];
         rc = rect[id];
     }
-    // lanes past P replicate the end offset so the search below never selects them
-    const uint32_t wave_begin = __shfl(off, 0, 64);
-    uint32_t last_valid_end = off + cnt;
-    {   // end of the wave's output range = max over lanes of off+cnt among valid lanes
-        uint32_t e = slot < P ? off + cnt : 0u;
+    // ---- prefix sum: inside the wave, over the workgroup's waves, over the preceding workgroups ----
+    uint32_t inc = cnt;   // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: wave sums are carried in 64 bits below
+    uint64_t inc64 = cnt;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o = __shfl_xor(e, d, 64);
-            e = e > o ? e : o;
-        }
-        last_valid_end = e;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc64, d, 64);
+        if (lane >= (uint32_t)d) inc64 += n;
     }
-    if (!(slot < P)) off = last_valid_end;
+    (void)inc;
+    if (lane == 63) s_wave[w] = inc64;
+    __syncthreads();
+    uint64_t wave_base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((uint32_t)i < w) wave_base += s_wave[i];
+    const uint64_t block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (threadIdx.x == 0) agent_store(&status[blockIdx.x], block_total + 1);
+    // look-back: every preceding workgroup's count (published as count + 1; 0 = not yet).  They were dispatched before
+    // this one, so waiting for them cannot deadlock.
+    uint64_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += DUP_THREADS) {
+        uint64_t v;
+        do { v = agent_load(&status[b]); } while (v == 0);
+        part += v - 1;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += (uint64_t)__shfl_xor((unsigned long long)part, d, 64);
+    __syncthreads();   // s_wave is reused
+    if (lane == 0) s_wave[w] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = base;
+        if (blockIdx.x == gridDim.x - 1) at_view(a.counters, a.g_stride, view)[CNT_NUM_RENDERED] = base + block_total;
+    }
+    __syncthreads();
+    if (a.keys == nullptr) return;   // count-only call (no binning arena yet)
+    const uint64_t off64 = s_base + wave_base + (inc64 - cnt);   // exclusive prefix of this Gaussian
+    KeyT* keys = at_view((KeyT*)a.keys, a.b_stride, view);
+    uint32_t* vals = at_view(a.vals, a.b_stride, view);
+
+    // the wave's output range [wave_begin, wave_end); positions at or beyond the capacity are dropped
+    const uint64_t wave_begin64 = (uint64_t)__shfl((unsigned long long)off64, 0, 64);
+    const uint64_t wave_end64 = (uint64_t)__shfl((unsigned long long)(off64 + cnt), 63, 64);
+    if (wave_begin64 >= (uint64_t)a.cap) return;
+    const uint32_t wave_begin = (uint32_t)wave_begin64;
+    const uint32_t wave_end = wave_end64 < (uint64_t)a.cap ? (uint32_t)wave_end64 : (uint32_t)a.cap;   // cap < 2^32
+    // offsets relative to the wave's begin (fit 32 bits: 64 Gaussians x < 2^28 tiles is rejected by the host long before)
+    uint32_t off = (uint32_t)(off64 - wave_begin64);
     s_off[w][lane] = off;
     s_id[w][lane] = id;
     s_rect[w][lane] = rc;
     __builtin_amdgcn_wave_barrier();
 
-    for (uint32_t p = wave_begin + lane; p < last_valid_end; p += 64) {
-        // largest s with s_off[s] <= p  (offsets are non-decreasing; zero-count entries are skipped)
+    for (uint32_t p = wave_begin + lane; p < wave_end; p += 64) {
+        const uint32_t rel = p - wave_begin;
+        // largest s with s_off[s] <= rel  (offsets are non-decreasing; zero-count entries are skipped)
         uint32_t lo = 0;
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
             const uint32_t cand = lo + step;
-            if (cand < 64 && s_off[w][cand] <= p) lo = cand;
+            if (cand < 64 && s_off[w][cand] <= rel) lo = cand;
         }
         const uint2 r = s_rect[w][lo];
         const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
         const uint32_t width = maxx - minx;
-        const uint32_t t = p - s_off[w][lo];
+        const uint32_t t = rel - s_off[w][lo];
         const uint32_t row = t / width, col = t - row * width;
-        keys[p] = (KeyT)((miny + row) * gridx + (minx + col));
+        keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
         vals[p] = s_id[w][lo];
     }
 }
 
-int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
-                     uint32_t* vals, bool key16)
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16)
 {
+    DupArgs a;
+    a.P = P;
+    a.gridx = (uint32_t)gridx;
+    a.order = B.g.dval[0];
+    a.tiles_touched = B.g.tiles_touched;
+    a.rect = B.g.rect;
+    a.dup_status = B.g.dup_status;
+    a.counters = B.g.counters;
+    a.g_stride = B.g_stride;
+    a.keys = B.b.key[0];
+    a.vals = B.b.val[0];
+    a.b_stride = B.b_stride;
+    a.cap = B.b.key[0] ? B.b.cap : 0;
+    const dim3 grid((unsigned)div_up(P, DUP_THREADS), B.V);
     if (key16)
-        hipLaunchKernelGGL(k_duplicate<uint16_t>, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
-                           g.tiles_touched, g.rect, (uint32_t)gridx, (uint16_t*)keys, vals);
+        hipLaunchKernelGGL(k_duplicate<uint16_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);
     else
-        hipLaunchKernelGGL(k_duplicate<uint32_t>, dim3((P + 255) / 256), dim3(256), 0, L.stream, P, order, g.dup_offset,
-                           g.tiles_touched, g.rect, (uint32_t)gridx, keys, vals);
+        hipLaunchKernelGGL(k_duplicate<uint32_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);
     return check_launch(L, "duplicate");
 }
 
+constexpr int RANGES_PER_THREAD = 4;
+
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges)
+__global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict__ counters, size_t g_stride, int64_t cap,
+                                                     const KeyT* __restrict__ keys, size_t b_stride, uint2* __restrict__ ranges,
+                                                     size_t iv_stride)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= R) return;
-    const uint32_t cur = keys[idx];
-    if (idx == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = keys[idx - 1];
-        if (cur != prev) {
-            ranges[prev].y = (uint32_t)idx;
-            ranges[cur].x = (uint32_t)idx;
+    const uint32_t view = blockIdx.y;
+    const uint64_t n64 = at_view(counters, g_stride, view)[CNT_NUM_RENDERED];
+    const int64_t R = n64 < (uint64_t)cap ? (int64_t)n64 : cap;
+    const int64_t base = (int64_t)blockIdx.x * (256 * RANGES_PER_THREAD);
+    if (base >= R) return;
+    keys = at_view(keys, b_stride, view);
+    ranges = at_view(ranges, iv_stride, view);
+#pragma unroll
+    for (int k = 0; k < RANGES_PER_THREAD; k++) {
+        const int64_t idx = base + k * 256 + threadIdx.x;
+        if (idx >= R) break;
+        const uint32_t cur = keys[idx];
+        if (idx == 0)
+            ranges[cur].x = 0;
+        else {
+            const uint32_t prev = keys[idx - 1];
+            if (cur != prev) {
+                ranges[prev].y = (uint32_t)idx;
+                ranges[cur].x = (uint32_t)idx;
+            }
         }
+        if (idx == R - 1) ranges[cur].y = (uint32_t)R;
     }
-    if (idx == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T, bool key16)
+// ranges[] was cleared at the start of the frame (k_preprocess, or the host on a retry)
+int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16)
 {
-    if (hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), L.stream) != hipSuccess) return GSR_ERR_HIP;
-    if (R > 0) {
-        if (key16)
-            hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R,
-                               (const uint16_t*)sorted_keys, ranges);
-        else
-            hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, L.stream, R, sorted_keys, ranges);
-        return check_launch(L, "tile_ranges");
-    }
-    return GSR_OK;
+    (void)T;
+    if (B.b.cap <= 0) return GSR_OK;
+    const dim3 grid((unsigned)div_up(B.b.cap, 256 * RANGES_PER_THREAD), B.V);
+    if (key16)
+        hipLaunchKernelGGL(k_tile_ranges<uint16_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap,
+                           (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride);
+    else
+        hipLaunchKernelGGL(k_tile_ranges<uint32_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap, sorted_keys,
+                           B.b_stride, B.iv.ranges, B.iv_stride);
+    return check_launch(L, "tile_ranges");
 }
 
 // ---- render launch order: tiles by descending work estimate (128 quarter-octave buckets) -------------
@@ -131,8 +225,11 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 // One 1024-thread workgroup: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
 // wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
 // one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
-__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order)
+__global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
+                                                     size_t iv_stride)
 {
+    ranges = at_view(ranges, iv_stride, blockIdx.x);
+    tile_order = at_view(tile_order, iv_stride, blockIdx.x);
     __shared__ uint32_t cnt[ORD_BUCKETS];
     __shared__ uint32_t cur[ORD_BUCKETS];
     const uint32_t lane = threadIdx.x & 63;
@@ -179,9 +276,9 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
     }
 }
 
-int launch_tile_order(const Launch& L, const ImageView& iv, int T)
+int launch_tile_order(const Launch& L, const Batch& B, int T)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, L.stream, T, iv.ranges, iv.tile_order);
+    hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride);
     return check_launch(L, "tile_order");
 }
 
@@ -190,10 +287,13 @@ int launch_tile_order(const Launch& L, const ImageView& iv, int T)
 // chunks of BWD_CHUNK entries; each (tile, chunk) is an independent backward work item (the forward left the per-pixel
 // state at every chunk boundary), so the longest serial walk in the backward kernel is BWD_CHUNK entries instead of a
 // whole list.  Items are emitted heaviest first with the same bucket scheme as tile_order; a tile's chunk number
-// BWD_MAX_CHUNKS-1 takes everything that is left.  item = tile | chunk << 20.
+// BWD_MAX_CHUNKS-1 takes everything that is left.  item = tile | chunk << BWD_TILE_BITS.
 __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,
-                                                    uint32_t* __restrict__ count)
+                                                    uint32_t* __restrict__ count, size_t iv_stride)
 {
+    need = at_view(need, iv_stride, blockIdx.x);
+    items = at_view(items, iv_stride, blockIdx.x);
+    count = at_view(count, iv_stride, blockIdx.x);
     __shared__ uint32_t cnt[ORD_BUCKETS];
     __shared__ uint32_t cur[ORD_BUCKETS];
     const uint32_t lane = threadIdx.x & 63;
@@ -213,9 +313,9 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __res
             } else {
                 if (n_full) {
                     const uint32_t slot = atomicAdd(&cur[full_bucket], n_full);
-                    for (uint32_t c = 0; c < n_full; c++) items[slot + c] = (uint32_t)t | (c << 20);
+                    for (uint32_t c = 0; c < n_full; c++) items[slot + c] = (uint32_t)t | (c << BWD_TILE_BITS);
                 }
-                if (rest) items[atomicAdd(&cur[work_bucket(rest)], 1u)] = (uint32_t)t | (n_full << 20);
+                if (rest) items[atomicAdd(&cur[work_bucket(rest)], 1u)] = (uint32_t)t | (n_full << BWD_TILE_BITS);
             }
         }
         __syncthreads();
@@ -237,9 +337,9 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __res
     }
 }
 
-int launch_bwd_items(const Launch& L, const ImageView& iv, int T)
+int launch_bwd_items(const Launch& L, const Batch& B, int T)
 {
-    hipLaunchKernelGGL(k_bwd_items, dim3(1), dim3(1024), 0, L.stream, T, iv.tile_need, iv.bwd_items, iv.bwd_count);
+    hipLaunchKernelGGL(k_bwd_items, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.tile_need, B.iv.bwd_items, B.iv.bwd_count, B.iv_stride);
     return check_launch(L, "bwd_items");
 }
 

@@ -5,6 +5,11 @@
 // rounding per written operation; +,-,*,/ and sqrt are correctly rounded under hipcc defaults), so
 // that integer outputs (radii, tile counts, sorted lists, ranges, n_contrib) are reproducible
 // bit-for-bit against the CPU oracle and the reference build ("Numerics").
+//
+// Views: every kernel works on a BATCH of V camera views of one cloud (V = 1 for the reference's per-view API).  The
+// scratch arenas of a batch are V identically laid out single-view arenas at a fixed byte stride, so a kernel finds
+// view v's arrays by adding v * stride to the view-0 pointers (at_view); the view index is blockIdx.y, or folded into
+// blockIdx.x where dispatch order matters (render kernels).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,13 +33,16 @@ constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // keys per workgroup per pass
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
-// ---- scan geometry ----------------------------------------------------------------------------
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int DUP_THREADS = 256;  // Gaussians per pair-emission workgroup (binning.hip)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T>
+__host__ __device__ __forceinline__ T* at_view(T* p, size_t stride_bytes, uint32_t view)
+{
+    return (T*)((uintptr_t)p + stride_bytes * view);
+}
 
 // Per-Gaussian packed splat record: what the render kernels gather per list entry.  Padded to one 64-B cache line, so a
 // gather touches exactly one line (a 48-B record straddles two half of the time) and preprocess writes whole lines.
@@ -42,6 +50,17 @@ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct __attribute__((aligned(64))) Splat {
     float4 q0, q1, q2, q3;
 };
+
+// grad_rec: [P][GRAD_REC_WORDS] accumulation records of the render backward, one 64-B line per Gaussian:
+//   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5..7 colour r g b  8 opacity  (9..15 unused)
+// The nine float atomics a (quadrant, entry) issues land in ONE cache line instead of four arrays' worth
+// (scripts/probe/atomic_probe.hip: 4x the atomic throughput).  Lives in the geometry arena, zeroed by the forward's
+// preprocess kernel (need_backward), so the backward needs no fill pass.
+constexpr int GRAD_REC_WORDS = 16;
+
+// counters[] slots (geometry arena, per view)
+constexpr int CNT_NUM_RENDERED = 0;  // true number of (tile, Gaussian) pairs, even when it exceeds the arena capacity
+constexpr int CNT_TRAP = 1;          // prefiltered = 1 but a Gaussian was culled
 
 // ---- arena views (device pointers carved out of the caller's opaque buffers) -------------------
 struct GeomView {
@@ -51,11 +70,13 @@ struct GeomView {
     uint8_t* clamped;         // [P] bit k = colour channel k was clamped at 0 (CR/forward.cu:66-69)
     uint32_t* dkey[2];        // [P] depth-bit keys, ping-pong (dkey[0] is also preprocess' output)
     uint32_t* dval[2];        // [P] Gaussian ids, ping-pong; after 4 passes dval[0] = ids in depth order
-    uint32_t* dup_offset;     // [P] exclusive prefix of tiles_touched in depth order
-    uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts
+    uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts (depth sort)
     uint32_t* totals;         // [RADIX]
-    uint32_t* scan_tmp;       // [nscan(P) + 1]
-    uint64_t* counters;       // [8]: 0 = num_rendered, 1 = trap flag
+    float* grad_rec;          // [P][GRAD_REC_WORDS]
+    uint64_t* dup_status;     // [ceil(P / DUP_THREADS)] pair count + 1 of each emission workgroup (binning.hip look-back)
+    uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
+    char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
+    size_t zero_bytes;
     size_t bytes;
 };
 
@@ -64,26 +85,34 @@ struct GeomView {
 constexpr int BWD_CHUNK = 1024;
 constexpr int BWD_CHUNK_SHIFT = 10;
 constexpr int BWD_MAX_CHUNKS = 16;   // per tile; the last one takes whatever is left
+constexpr int BWD_TILE_BITS = 28;    // item = tile | chunk << 28 (check_params limits images to 2^28 tiles)
 
+// The binning arena is carved by CAPACITY (pairs), not by the frame's pair count: the count only exists on the device
+// while the frame is being enqueued (no host round trip), and forward and backward must carve identically, so both derive
+// the capacity from the arena's byte size (bin_capacity_from_bytes).
 struct BinView {
-    uint32_t* key[2];  // [R] tile ids, ping-pong (stored as uint16_t when the image has <= 65536 tiles)
-    uint32_t* val[2];  // [R] Gaussian ids, ping-pong
-    uint32_t* hist;    // [RADIX * nblk(R)]
+    uint32_t* key[2];  // [cap] tile ids, ping-pong (stored as uint16_t when the image has <= 65536 tiles)
+    uint32_t* val[2];  // [cap] Gaussian ids, ping-pong
+    uint32_t* hist;    // [RADIX * nblk(cap)]
     uint32_t* totals;  // [RADIX]
-    float4* ckpt;      // [(R / BWD_CHUNK + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
+    float4* ckpt;      // [(cap / BWD_CHUNK + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
                        // range.x + k * BWD_CHUNK, slot (range.x >> BWD_CHUNK_SHIFT) + k  (unique: lists do not overlap)
+    int64_t cap;
     size_t bytes;
 };
 
 struct ImageView {
-    uint2* ranges;        // [T]
+    uint2* ranges;        // [T]          } cleared by k_preprocess at the start of every frame
+    uint32_t* tile_need;  // [T] entries walked by the forward render }
+    uint32_t* bwd_count;  // [4] number of backward items             }
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
     uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
-    uint32_t* tile_need;  // [T] entries walked by the forward render
-    float* accum;         // [3N] colour accumulated by the forward render, without the background term
-    uint32_t* bwd_items;  // [BWD_MAX_CHUNKS * T] backward work items: tile | chunk << 20, heaviest first
-    uint32_t* bwd_count;  // [4] number of items
+    float* accum;         // [3N] colour accumulated by the forward render, without the background term (only written
+                          //      for quadrants that crossed a BWD_CHUNK boundary: the only ones whose backward reads it)
+    uint32_t* bwd_items;  // [BWD_MAX_CHUNKS * T] backward work items: tile | chunk << BWD_TILE_BITS, heaviest first
+    char* zero_begin;
+    size_t zero_bytes;
     size_t bytes;
 };
 
@@ -100,7 +129,6 @@ inline GeomView geom_view(void* base, int P)
     char* cur = reinterpret_cast<char*>(base);
     const size_t p = (size_t)(P > 0 ? P : 1);
     const size_t nblk = (size_t)div_up((int64_t)p, RS_TILE);
-    const size_t nscan = (size_t)div_up((int64_t)p, SCAN_TILE);
     carve(cur, g.splat, p);
     carve(cur, g.tiles_touched, p);
     carve(cur, g.rect, p);
@@ -109,20 +137,22 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.dkey[1], p);
     carve(cur, g.dval[0], p);
     carve(cur, g.dval[1], p);
-    carve(cur, g.dup_offset, p);
     carve(cur, g.hist, RADIX * nblk);
     carve(cur, g.totals, (size_t)RADIX);
-    carve(cur, g.scan_tmp, nscan + 1);
+    carve(cur, g.grad_rec, p * GRAD_REC_WORDS);
+    g.zero_begin = cur;
+    carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS));
+    g.zero_bytes = (size_t)(cur - g.zero_begin);
     carve(cur, g.counters, (size_t)8);
     g.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return g;
 }
 
-inline BinView bin_view(void* base, int64_t R)
+inline BinView bin_view(void* base, int64_t cap)
 {
     BinView b;
     char* cur = reinterpret_cast<char*>(base);
-    const size_t r = (size_t)(R > 0 ? R : 1);
+    const size_t r = (size_t)(cap > 0 ? cap : 1);
     const size_t nblk = (size_t)div_up((int64_t)r, RS_TILE);
     carve(cur, b.key[0], r);
     carve(cur, b.key[1], r);
@@ -131,8 +161,21 @@ inline BinView bin_view(void* base, int64_t R)
     carve(cur, b.hist, RADIX * nblk);
     carve(cur, b.totals, (size_t)RADIX);
     carve(cur, b.ckpt, (r / BWD_CHUNK + 2) * 256);
+    b.cap = (int64_t)r;
     b.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return b;
+}
+
+// largest capacity whose arena fits `bytes` (bin_view(cap).bytes is non-decreasing in cap); 0 if not even one pair fits
+inline int64_t bin_capacity_from_bytes(size_t bytes)
+{
+    if (bin_view(nullptr, 1).bytes > bytes) return 0;
+    int64_t lo = 1, hi = (int64_t)(bytes / 16) + 1;   // 16 B per pair is a lower bound of the per-pair cost
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo + 1) / 2;
+        if (bin_view(nullptr, mid).bytes <= bytes) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 inline ImageView image_view(void* base, int W, int H)
@@ -141,14 +184,16 @@ inline ImageView image_view(void* base, int W, int H)
     char* cur = reinterpret_cast<char*>(base);
     const size_t N = (size_t)W * (size_t)H;
     const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * (size_t)((H + TILE_Y - 1) / TILE_Y);
+    v.zero_begin = cur;
     carve(cur, v.ranges, T ? T : 1);
+    carve(cur, v.tile_need, T ? T : 1);
+    carve(cur, v.bwd_count, (size_t)4);
+    v.zero_bytes = (size_t)(cur - v.zero_begin);
     carve(cur, v.final_T, N ? N : 1);
     carve(cur, v.n_contrib, N ? N : 1);
     carve(cur, v.tile_order, T ? T : 1);
-    carve(cur, v.tile_need, T ? T : 1);
     carve(cur, v.accum, 3 * (N ? N : 1));
     carve(cur, v.bwd_items, (size_t)BWD_MAX_CHUNKS * (T ? T : 1));
-    carve(cur, v.bwd_count, (size_t)4);
     v.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return v;
 }
@@ -172,42 +217,63 @@ struct Launch {
     int debug;
 };
 
+// One batch of V views: the view-0 carving of each arena plus the byte stride to the next view's arena.
+struct Batch {
+    int V;
+    GeomView g;
+    size_t g_stride;
+    ImageView iv;
+    size_t iv_stride;
+    BinView b;          // carved by capacity (b.cap); b.key[0] == nullptr when no binning arena was given
+    size_t b_stride;
+};
+
 int check_launch(const Launch& L, const char* what);  // api.hip
 
 // preprocess.hip
-int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, int* radii);
-int launch_recolor(const Launch& L, const gsr_params& p, const GeomView& g);
+int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int* radii);
+int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B);
 int launch_mark_visible(const Launch& L, int P, const float* means3D, const float* view, uint8_t* present);
 // sort.hip
+// Stable LSD radix sort of `V` independent (u32 key, u32 value) problems laid out at `stride` bytes from each other.
+// n_dev != NULL: the element count of view v is min(*at_view(n_dev, n_stride, v), cap) (device resident); else cap.
 // key16: the key arrays hold uint16_t (tile ids of images up to 65536 tiles: 14 instead of 20 B per pair per pass)
-int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32_t* val[2], bool iota_vals,
-                            int end_bit, uint32_t* hist, uint32_t* totals, int* result_buffer, bool key16 = false);
+struct SortJob {
+    uint32_t* key[2];
+    uint32_t* val[2];
+    uint32_t* hist;
+    uint32_t* totals;
+    size_t stride;
+    const uint64_t* n_dev;
+    size_t n_stride;
+    int64_t cap;
+    int V;
+};
+int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16 = false);
 inline bool tile_keys16(int T) { return T <= 65536; }
-int launch_offsets_scan(const Launch& L, int P, const uint32_t* order, const uint32_t* tiles_touched,
-                        uint32_t* dup_offset, uint32_t* scan_tmp, uint64_t* total_out);
 // binning.hip
-int launch_duplicate(const Launch& L, int P, const GeomView& g, const uint32_t* order, int gridx, uint32_t* keys,
-                     uint32_t* vals, bool key16);
-int launch_tile_ranges(const Launch& L, int64_t R, const uint32_t* sorted_keys, uint2* ranges, int T, bool key16);
-int launch_tile_order(const Launch& L, const ImageView& iv, int T);
-int launch_bwd_items(const Launch& L, const ImageView& iv, int T);
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16);
+int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16);
+int launch_tile_order(const Launch& L, const Batch& B, int T);
+int launch_bwd_items(const Launch& L, const Batch& B, int T);
 // render_fwd.hip / render_bwd.hip
-// ckpt: chunk-boundary state for the backward pass (NULL: not recorded, e.g. inference / colour-only re-render)
-int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                          const ImageView& iv, float* out_color, float4* ckpt);
-// grad_rec: [P][GRAD_REC_WORDS] zero-filled accumulation records, one 64-B line per Gaussian:
-//   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5..7 colour r g b  8 opacity  (9..15 unused)
-// The nine float atomics a (quadrant, entry) issues land in ONE cache line instead of four arrays' worth
-// (scripts/probe/atomic_probe.hip: 4x the atomic throughput).
-constexpr int GRAD_REC_WORDS = 16;
-int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* grad_rec);
+// point_list: view 0's sorted ids (binning arena); with_ckpt: record the chunk-boundary state for the backward pass
+int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
+                          bool with_ckpt);
+int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix);
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
 // preprocess_bwd.hip
-// reads grad_rec; writes the user-facing dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3] (copies of the record's
-// fields) for every Gaussian besides the geometric gradients
-int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,
-                               const float* grad_rec, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot);
+// reads grad_rec of every view; writes the user-facing gradients summed over the views of the batch
+int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch& B, const int* radii, float* dL_dmean2D,
+                               float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                               float* dL_dscale, float* dL_drot);
+
+// device helper: clear [p, p + bytes) (16-B aligned, multiple of 16) with the calling grid's threads
+__device__ __forceinline__ void zero_region(char* p, size_t bytes, size_t gtid, size_t nthreads)
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const size_t n = bytes / 16;
+    for (size_t i = gtid; i < n; i += nthreads) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 
 }  // namespace gsr

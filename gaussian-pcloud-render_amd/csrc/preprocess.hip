@@ -66,27 +66,40 @@ struct PreArgs {
     int prefiltered, need_backward;
     uint32_t gridx, gridy;
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
-    const float *view, *proj, *campos;
+    const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
     Splat* splat;
     uint32_t* tiles_touched;
     uint2* rect;
     uint8_t* clamped;
     uint32_t* dkey;
-    int* radii;
+    float* grad_rec;
     uint64_t* counters;
+    char* g_zero;                         // per-frame cleared regions of the geometry / image arenas
+    size_t g_zero_bytes, g_stride;
+    char* iv_zero;
+    size_t iv_zero_bytes, iv_stride;
+    int* radii;                           // [V][P]
 };
 
 __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 {
+    const uint32_t vw = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    // this frame's bookkeeping that later kernels accumulate into (prefix-sum status words; tile ranges, consumed-entry
+    // counts, backward item count) is cleared here, so a frame needs no memset launches
+    {
+        const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+        zero_region(a.g_zero + a.g_stride * vw, a.g_zero_bytes, gtid, nthr);
+        zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
+    }
     if (idx >= a.P) return;
 
     // uniform data: 35 scalar loads, served by the scalar cache
     float view[16], proj[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        view[i] = a.view[i];
-        proj[i] = a.proj[i];
+        view[i] = a.view[16 * vw + i];
+        proj[i] = a.proj[16 * vw + i];
     }
 
     int radius_out = 0;
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     const V3 p_view = xform_point_4x3(p_orig, view);
 
     if (p_view.z <= 0.2f) {
-        if (a.prefiltered) a.counters[1] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
+        if (a.prefiltered) at_view(a.counters, a.g_stride, vw)[CNT_TRAP] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
     } else {
         const float hx = ((proj[0] * p_orig.x + proj[4] * p_orig.y) + proj[8] * p_orig.z) + proj[12];
         const float hy = ((proj[1] * p_orig.x + proj[5] * p_orig.y) + proj[9] * p_orig.z) + proj[13];
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                 if (a.colors_precomp) {
                     rgb = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
                 } else {
-                    const V3 cam = v3(a.campos[0], a.campos[1], a.campos[2]);
+                    const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
                     rgb = sh_to_rgb(a.D, p_orig, cam, a.shs + (size_t)idx * a.M * 3, &cmask);
                 }
                 radius_out = (int)my_radius;
@@ -161,18 +174,26 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         }
     }
 
-    a.radii[idx] = radius_out;
-    a.tiles_touched[idx] = tiles;
-    a.dkey[idx] = key;
-    a.rect[idx] = rect;
-    a.splat[idx].q0 = s.q0;   // (q3 is padding: never written, never read)
-    a.splat[idx].q1 = s.q1;
-    a.splat[idx].q2 = s.q2;
-    if (a.need_backward) a.clamped[idx] = (uint8_t)cmask;
+    a.radii[(size_t)vw * a.P + idx] = radius_out;
+    at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
+    at_view(a.dkey, a.g_stride, vw)[idx] = key;
+    at_view(a.rect, a.g_stride, vw)[idx] = rect;
+    Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
+    sp->q0 = s.q0;   // (q3 is padding: never written, never read)
+    sp->q1 = s.q1;
+    sp->q2 = s.q2;
+    if (a.need_backward) {
+        at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
+        // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
+        float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.g_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
+    }
 }
 
-int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, int* radii)
+int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int* radii)
 {
+    const GeomView& g = B.g;
     PreArgs a;
     a.P = p.P; a.D = p.D; a.M = p.M; a.W = p.W; a.H = p.H;
     a.tanfovx = p.tanfovx; a.tanfovy = p.tanfovy;
@@ -187,9 +208,11 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, i
     a.scales = p.scales; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
     a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
     a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.rect = g.rect; a.clamped = g.clamped;
-    a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters;
+    a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters; a.grad_rec = g.grad_rec;
+    a.g_zero = g.zero_begin; a.g_zero_bytes = g.zero_bytes; a.g_stride = B.g_stride;
+    a.iv_zero = B.iv.zero_begin; a.iv_zero_bytes = B.iv.zero_bytes; a.iv_stride = B.iv_stride;
     const int blocks = (p.P + 255) / 256;
-    hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(256), 0, L.stream, a);
+    hipLaunchKernelGGL(k_preprocess, dim3(blocks, B.V), dim3(256), 0, L.stream, a);
     return check_launch(L, "preprocess");
 }
 
@@ -202,8 +225,12 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const GeomView& g, i
 __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const float* __restrict__ means3D,
                                                  const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                                                  const float* __restrict__ campos, const uint32_t* __restrict__ tiles_touched,
-                                                 Splat* __restrict__ splat)
+                                                 Splat* __restrict__ splat, size_t g_stride)
 {
+    const uint32_t vw = blockIdx.y;
+    tiles_touched = at_view(tiles_touched, g_stride, vw);
+    splat = at_view(splat, g_stride, vw);
+    if (campos) campos += 3 * vw;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || tiles_touched[idx] == 0) return;
     V3 rgb;
@@ -220,10 +247,10 @@ __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const floa
     rec[8] = rgb.z;  // q2.x
 }
 
-int launch_recolor(const Launch& L, const gsr_params& p, const GeomView& g)
+int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B)
 {
-    hipLaunchKernelGGL(k_recolor, dim3((p.P + 255) / 256), dim3(256), 0, L.stream, p.P, p.D, p.M, p.means3D, p.shs,
-                       p.colors_precomp, p.campos, g.tiles_touched, g.splat);
+    hipLaunchKernelGGL(k_recolor, dim3((p.P + 255) / 256, B.V), dim3(256), 0, L.stream, p.P, p.D, p.M, p.means3D, p.shs,
+                       p.colors_precomp, p.campos, B.g.tiles_touched, B.g.splat, B.g_stride);
     return check_launch(L, "recolor");
 }
 

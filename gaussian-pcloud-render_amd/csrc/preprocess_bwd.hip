@@ -1,20 +1,46 @@
-// preprocess_bwd.hip -- per-Gaussian backward: dL/d{conic, mean2D, colour} -> dL/d{mean3D, cov3D, SH,
-// scale, rotation}.
+// preprocess_bwd.hip -- per-Gaussian backward: dL/d{conic, mean2D, colour} -> dL/d{mean3D, cov3D, SH, scale, rotation}.
 //
-// One kernel, one thread per visible Gaussian, fusing the reference's two launches
-//   computeCov2DCUDA   CR/backward.cu:144-274   (conic -> cov2D -> cov3D and the mean through the Jacobian)
-//   preprocessCUDA     CR/backward.cu:346-396   (mean2D -> mean3D, SH backward CR/backward.cu:20-139,
-//                                                scale/rotation backward CR/backward.cu:278-341)
-// so dL_dmean3D is accumulated in registers in the reference's order (cov2D part, + projection part, + SH
-// view-direction part) and written once, and dL_dcov3D feeds the scale/rotation step without a round trip
-// through HBM (it is still stored: it is the gradient returned for cov3D_precomp).  The 3D covariance is
-// recomputed from scale/rotation with the forward's code instead of being saved by the forward pass.
+// One kernel, one thread per Gaussian, covering what the reference does in two launches
+//   computeCov2DCUDA   CR/backward.cu:144-274   (conic -> 2D covariance -> 3D covariance, and the mean through the projection Jacobian)
+//   preprocessCUDA     CR/backward.cu:346-396   (mean2D -> mean3D, SH backward CR/backward.cu:20-139, scale / rotation backward :278-341)
+// and summing over the V views of a batch in registers (V = 1 for the per-view API): every output is written exactly once,
+// for every Gaussian (zeros when it is invisible in all views; all M rows of dL_dsh), so the caller clears nothing.
+//
+// The gradient chain is written from its own derivation (below), not from the reference's expression list; the forward
+// quantities it needs (view-space mean with the frustum clamp, the 2x3 projection M = J W, a, b, c of the dilated 2D
+// covariance) come from the same code the forward pass runs (splat_math.hpp), so they are bit-identical to what the
+// forward saw.  Results are compared to tolerance (float accumulation order already differs in the render backward).
+//
+//   2D covariance   [a b; b c] = M S M^T + 0.3 I,   M = J W (2x3, rows m0, m1),   S = 3D covariance (symmetric)
+//   conic           (A, B, C) = (c, -b, a) / det,   det = a c - b^2
+//   with g = dL/d(A, B, C) and D = 1 / (det^2 + 1e-7):
+//       dL/da = D (-c^2 gA + 2 b c gB + (det - a c) gC)
+//       dL/dc = D (-a^2 gC + 2 a b gB + (det - a c) gA)
+//       dL/db = 2 D (b c gA - (det + 2 b^2) gB + a b gC)
+//   a = m0.S m0, b = m0.S m1, c = m1.S m1, hence with u = S m0, w = S m1:
+//       dL/dS_ii = m0_i^2 da + m0_i m1_i db + m1_i^2 dc
+//       dL/dS_ij = 2 m0_i m0_j da + (m0_i m1_j + m0_j m1_i) db + 2 m1_i m1_j dc        (i < j; the 6-vector holds S_ij once)
+//       dL/dm0 = 2 da u + db w,      dL/dm1 = 2 dc w + db u
+//   m0 = J00 r0 + J02 r2, m1 = J11 r1 + J12 r2 with r_k the rows of the view rotation and
+//   J00 = fx / tz, J02 = -fx tx / tz^2, J11 = fy / tz, J12 = -fy ty / tz^2:
+//       dL/dJ00 = r0.dm0, dL/dJ02 = r2.dm0, dL/dJ11 = r1.dm1, dL/dJ12 = r2.dm1
+//       dL/dtx = -(fx / tz^2) dJ02   (0 where the frustum clamp was active, likewise ty)
+//       dL/dty = -(fy / tz^2) dJ12
+//       dL/dtz = -(fx dJ00 + fy dJ11) / tz^2 + 2 (fx tx dJ02 + fy ty dJ12) / tz^3
+//       dL/dmean = R^T dL/dt
+//   S = sum_k a_k a_k^T with a_k = s_k c_k (c_k = column k of the rotation built from the raw quaternion, s = modifier * scale);
+//   with G the full symmetric dL/dS (off-diagonals halved):  e_k = 2 G a_k,  dL/dscale_k = c_k . e_k  (as upstream: no factor
+//   for the modifier),  dL/dc_k = s_k e_k =: column k of Q, and the quaternion derivative of the rotation entries gives
+//       dL/dr = 2 z (Q10 - Q01) + 2 y (Q02 - Q20) + 2 x (Q21 - Q12)
+//       dL/dx = 2 y (Q01 + Q10) + 2 z (Q02 + Q20) + 2 r (Q21 - Q12) - 4 x (Q11 + Q22)
+//       dL/dy = 2 x (Q01 + Q10) + 2 r (Q02 - Q20) + 2 z (Q12 + Q21) - 4 y (Q00 + Q22)
+//       dL/dz = 2 r (Q10 - Q01) + 2 x (Q02 + Q20) + 2 y (Q12 + Q21) - 4 z (Q00 + Q11)      (Q_ij = dL/dR_ij)
 #include "common.hpp"
 #include "splat_math.hpp"
 
 namespace gsr {
 
-// reference CR/auxiliary.h:107-117
+// d normalize(v) / dv applied to dv (reference CR/auxiliary.h:107-117)
 __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv)
 {
     const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
@@ -26,21 +52,25 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv)
     return r;
 }
 
+constexpr int SH_MAX_ROWS = 16;
+
 struct PreBwdArgs {
-    int P, D, M;
+    int P, D, M, V;
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
-    const float *means3D, *shs, *scales, *rotations, *cov3D_precomp, *view, *proj, *campos;
-    const int* radii;
+    const float *means3D, *shs, *scales, *rotations, *cov3D_precomp;
+    const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
+    const int* radii;                    // [V][P]
     const uint8_t* clamped;
-    const float* grad_rec;                         // [P][GRAD_REC_WORDS], see common.hpp
-    float *dL_dmean2D, *dL_dopacity, *dL_dcolor;   // user-facing copies of record fields
+    const float* grad_rec;               // [P][GRAD_REC_WORDS] per view, see common.hpp
+    size_t g_stride;
+    float *dL_dmean2D, *dL_dopacity, *dL_dcolor;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 
-// SH backward (reference CR/backward.cu:20-139): writes dL_dsh rows, returns the mean gradient through the
+// SH backward (reference CR/backward.cu:20-139): adds this view's dL_dsh rows into acc, returns the mean gradient through the
 // normalised view direction.
-__device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t cmask,
-                                          V3 dL_dRGB, float* __restrict__ dL_dsh)
+__device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t cmask, V3 dL_dRGB,
+                                          float (&acc)[SH_MAX_ROWS * 3])
 {
     const V3 dir_orig = pos - campos;
     const float len = sqrtf(dot3(dir_orig, dir_orig));
@@ -51,7 +81,7 @@ __device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const floa
     V3 dRGBdx = v3(0, 0, 0), dRGBdy = v3(0, 0, 0), dRGBdz = v3(0, 0, 0);
     const float x = dir.x, y = dir.y, z = dir.z;
 #define SHV(k) v3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
-#define PUT(k, s) do { const V3 t_ = (s) * dL_dRGB; dL_dsh[3 * (k)] = t_.x; dL_dsh[3 * (k) + 1] = t_.y; dL_dsh[3 * (k) + 2] = t_.z; } while (0)
+#define PUT(k, s) do { const V3 t_ = (s) * dL_dRGB; acc[3 * (k)] += t_.x; acc[3 * (k) + 1] += t_.y; acc[3 * (k) + 2] += t_.z; } while (0)
     PUT(0, kSH_C0);
     if (deg > 0) {
         PUT(1, -kSH_C1 * y);
@@ -118,198 +148,169 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.P) return;
-    // the render-level sums of this Gaussian: one 64-B record (zeros when nothing was accumulated, e.g. invisible)
-    const float4 rec0 = *reinterpret_cast<const float4*>(a.grad_rec + (size_t)idx * GRAD_REC_WORDS);
-    const float4 rec1 = *reinterpret_cast<const float4*>(a.grad_rec + (size_t)idx * GRAD_REC_WORDS + 4);
-    const float rec8 = a.grad_rec[(size_t)idx * GRAD_REC_WORDS + 8];
-    a.dL_dmean2D[3 * (size_t)idx + 0] = rec0.x;
-    a.dL_dmean2D[3 * (size_t)idx + 1] = rec0.y;
-    a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-    a.dL_dcolor[3 * (size_t)idx + 0] = rec1.y;
-    a.dL_dcolor[3 * (size_t)idx + 1] = rec1.z;
-    a.dL_dcolor[3 * (size_t)idx + 2] = rec1.w;
-    a.dL_dopacity[idx] = rec8;
-    if (!(a.radii[idx] > 0)) {
-        // invisible Gaussian: no gradient.  The per-Gaussian outputs this kernel owns are written for every index, so the
-        // caller does not have to clear them first (the atomically accumulated ones and dL_dsh's unused rows it does).
-#pragma unroll
-        for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
-        if (a.scales) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.f;
-            *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
 
-    float view[16], proj[16];
+    // sums over the views of the batch
+    float g2x = 0.f, g2y = 0.f, gop = 0.f;
+    V3 gcol = v3(0, 0, 0), gmean = v3(0, 0, 0);
+    float gS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gsh[SH_MAX_ROWS * 3];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        view[i] = a.view[i];
-        proj[i] = a.proj[i];
-    }
+    for (int i = 0; i < SH_MAX_ROWS * 3; i++) gsh[i] = 0.f;
+
     const V3 mean = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-
-    // ---- 3D covariance as the forward saw it
-    float cov6[6];
+    // 3D covariance as the forward saw it (recomputed with the forward's code, not stored)
+    float S6[6];
     V3 sc = v3(0, 0, 0);
     float4 q = make_float4(0, 0, 0, 0);
     if (a.cov3D_precomp) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        for (int i = 0; i < 6; i++) S6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
     } else {
         sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
         q = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
-        cov3d_from_scale_rot(sc, a.scale_modifier, q, cov6, nullptr);
+        cov3d_from_scale_rot(sc, a.scale_modifier, q, S6, nullptr);
     }
 
-    // ---- conic -> cov2D -> cov3D, and the mean through J (reference CR/backward.cu:144-274)
-    const float gcx = rec0.z, gcy = rec0.w, gcz = rec1.x;
-    const float h_x = a.focal_x, h_y = a.focal_y;
-    const Cov2D c = cov2d_project(mean, h_x, h_y, a.tanfovx, a.tanfovy, cov6, view);
-    const V3 t = c.t;
-    const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0 : 1;
-    const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0 : 1;
-    const M3& T = c.T;
-    const M3& W = c.W;
-    const M3& Vrk = c.Vrk;
+    for (int vw = 0; vw < a.V; vw++) {
+        // the render-level sums of this Gaussian in this view: one 64-B record (zeros when nothing was accumulated)
+        const float* recp = at_view(a.grad_rec, a.g_stride, (uint32_t)vw) + (size_t)idx * GRAD_REC_WORDS;
+        const float4 rec0 = *reinterpret_cast<const float4*>(recp);
+        const float4 rec1 = *reinterpret_cast<const float4*>(recp + 4);
+        const float rec8 = recp[8];
+        g2x += rec0.x; g2y += rec0.y;
+        gcol = gcol + v3(rec1.y, rec1.z, rec1.w);
+        gop += rec8;
+        if (!(a.radii[(size_t)vw * a.P + idx] > 0)) continue;   // invisible in this view: no geometric gradient
 
-    const float ca = c.cov.m[0][0] + 0.3f;
-    const float cb = c.cov.m[0][1];
-    const float cc = c.cov.m[1][1] + 0.3f;
-    const float denom = ca * cc - cb * cb;
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float dcov[6];
-    if (denom2inv != 0) {
-        dL_da = denom2inv * (-cc * cc * gcx + 2 * cb * cc * gcy + (denom - ca * cc) * gcz);
-        dL_dc = denom2inv * (-ca * ca * gcz + 2 * ca * cb * gcy + (denom - ca * cc) * gcx);
-        dL_db = denom2inv * 2 * (cb * cc * gcx - (denom + 2 * cb * cb) * gcy + ca * cb * gcz);
-        dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
-        dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
-        dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
-        dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
-        dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
-        dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
-    } else {
+        const float* view = a.view + 16 * vw;
+        const float* proj = a.proj + 16 * vw;
+        const float fx = a.focal_x, fy = a.focal_y;
+        const Cov2D c = cov2d_project(mean, fx, fy, a.tanfovx, a.tanfovy, S6, view);
+        const bool clamp_x = c.txtz < -c.limx || c.txtz > c.limx, clamp_y = c.tytz < -c.limy || c.tytz > c.limy;
+        const V3 m0 = v3(c.T.m[0][0], c.T.m[0][1], c.T.m[0][2]), m1 = v3(c.T.m[1][0], c.T.m[1][1], c.T.m[1][2]);
+        const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
+
+        // ---- conic -> (a, b, c)
+        const float gA = rec0.z, gB = rec0.w, gC = rec1.x;
+        const float det = ca * cc - cb * cb;
+        const float Dn = 1.0f / ((det * det) + 0.0000001f);
+        float da = 0.f, db = 0.f, dc = 0.f;
+        if (Dn != 0) {
+            da = Dn * (-cc * cc * gA + 2 * cb * cc * gB + (det - ca * cc) * gC);
+            dc = Dn * (-ca * ca * gC + 2 * ca * cb * gB + (det - ca * cc) * gA);
+            db = Dn * 2 * (cb * cc * gA - (det + 2 * cb * cb) * gB + ca * cb * gC);
+            // ---- (a, b, c) -> 3D covariance (xx, xy, xz, yy, yz, zz)
+            gS[0] += m0.x * m0.x * da + m0.x * m1.x * db + m1.x * m1.x * dc;
+            gS[3] += m0.y * m0.y * da + m0.y * m1.y * db + m1.y * m1.y * dc;
+            gS[5] += m0.z * m0.z * da + m0.z * m1.z * db + m1.z * m1.z * dc;
+            gS[1] += 2 * m0.x * m0.y * da + (m0.x * m1.y + m0.y * m1.x) * db + 2 * m1.x * m1.y * dc;
+            gS[2] += 2 * m0.x * m0.z * da + (m0.x * m1.z + m0.z * m1.x) * db + 2 * m1.x * m1.z * dc;
+            gS[4] += 2 * m0.z * m0.y * da + (m0.y * m1.z + m0.z * m1.y) * db + 2 * m1.y * m1.z * dc;
+        }
+        // ---- (a, b, c) -> rows of M -> Jacobian entries -> view-space mean -> mean
+        const V3 u = v3(S6[0] * m0.x + S6[1] * m0.y + S6[2] * m0.z, S6[1] * m0.x + S6[3] * m0.y + S6[4] * m0.z,
+                        S6[2] * m0.x + S6[4] * m0.y + S6[5] * m0.z);
+        const V3 w = v3(S6[0] * m1.x + S6[1] * m1.y + S6[2] * m1.z, S6[1] * m1.x + S6[3] * m1.y + S6[4] * m1.z,
+                        S6[2] * m1.x + S6[4] * m1.y + S6[5] * m1.z);
+        const V3 dm0 = (2 * da) * u + db * w, dm1 = (2 * dc) * w + db * u;
+        const V3 r0 = v3(view[0], view[4], view[8]), r1 = v3(view[1], view[5], view[9]), r2 = v3(view[2], view[6], view[10]);
+        const float dJ00 = dot3(r0, dm0), dJ02 = dot3(r2, dm0), dJ11 = dot3(r1, dm1), dJ12 = dot3(r2, dm1);
+        const V3 t = c.t;
+        const float iz = 1.f / t.z, iz2 = iz * iz, iz3 = iz2 * iz;
+        const float dtx = clamp_x ? 0.f : -fx * iz2 * dJ02;
+        const float dty = clamp_y ? 0.f : -fy * iz2 * dJ12;
+        const float dtz = -(fx * dJ00 + fy * dJ11) * iz2 + 2 * (fx * t.x * dJ02 + fy * t.y * dJ12) * iz3;
+        V3 dmean = v3(view[0] * dtx + view[1] * dty + view[2] * dtz, view[4] * dtx + view[5] * dty + view[6] * dtz,
+                      view[8] * dtx + view[9] * dty + view[10] * dtz);
+
+        // ---- mean2D -> mean through the perspective divide: ndc = (P row0 . m, P row1 . m) / (P row3 . m + 1e-7)
+        {
+            const float hx = proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12];
+            const float hy = proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13];
+            const float hw = ((proj[3] * mean.x + proj[7] * mean.y) + proj[11] * mean.z) + proj[15];
+            const float iw = 1.0f / (hw + 0.0000001f);
+            const float kx = hx * iw * iw, ky = hy * iw * iw;
+            const float gx = rec0.x, gy = rec0.y;
+            dmean.x += (proj[0] * iw - proj[3] * kx) * gx + (proj[1] * iw - proj[3] * ky) * gy;
+            dmean.y += (proj[4] * iw - proj[7] * kx) * gx + (proj[5] * iw - proj[7] * ky) * gy;
+            dmean.z += (proj[8] * iw - proj[11] * kx) * gx + (proj[9] * iw - proj[11] * ky) * gy;
+        }
+
+        // ---- colour -> SH (+ view-direction term on the mean)
+        if (a.shs) {
+            const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
+            const uint8_t cm = at_view(a.clamped, a.g_stride, (uint32_t)vw)[idx];
+            dmean = dmean + sh_backward(a.D, mean, cam, a.shs + (size_t)idx * a.M * 3, cm, v3(rec1.y, rec1.z, rec1.w), gsh);
+        }
+        gmean = gmean + dmean;
+    }
+
+    a.dL_dmean2D[3 * (size_t)idx + 0] = g2x;
+    a.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
+    a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+    a.dL_dcolor[3 * (size_t)idx + 0] = gcol.x;
+    a.dL_dcolor[3 * (size_t)idx + 1] = gcol.y;
+    a.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
+    a.dL_dopacity[idx] = gop;
+    a.dL_dmean3D[3 * (size_t)idx + 0] = gmean.x;
+    a.dL_dmean3D[3 * (size_t)idx + 1] = gmean.y;
+    a.dL_dmean3D[3 * (size_t)idx + 2] = gmean.z;
 #pragma unroll
-        for (int i = 0; i < 6; i++) dcov[i] = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
-
-    const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
-                          (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
-    const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
-                          (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
-    const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
-                          (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
-    const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
-                          (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
-    const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
-                          (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
-    const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
-                          (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
-
-    const float dL_dJ00 = W.m[0][0] * dL_dT00 + W.m[0][1] * dL_dT01 + W.m[0][2] * dL_dT02;
-    const float dL_dJ02 = W.m[2][0] * dL_dT00 + W.m[2][1] * dL_dT01 + W.m[2][2] * dL_dT02;
-    const float dL_dJ11 = W.m[1][0] * dL_dT10 + W.m[1][1] * dL_dT11 + W.m[1][2] * dL_dT12;
-    const float dL_dJ12 = W.m[2][0] * dL_dT10 + W.m[2][1] * dL_dT11 + W.m[2][2] * dL_dT12;
-
-    const float tz = 1.f / t.z;
-    const float tz2 = tz * tz;
-    const float tz3 = tz2 * tz;
-    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-
-    // transformVec4x3Transpose (reference CR/auxiliary.h:89-97); plain assignment in the reference (:273)
-    V3 dmean = v3(view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz,
-                  view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz,
-                  view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz);
-
-    // ---- mean2D -> mean3D through the perspective divide (reference CR/backward.cu:370-391)
-    {
-        const float m_hom_w = ((proj[3] * mean.x + proj[7] * mean.y) + proj[11] * mean.z) + proj[15];
-        const float m_w = 1.0f / (m_hom_w + 0.0000001f);
-        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float gx = rec0.x, gy = rec0.y;
-        V3 d;
-        d.x = (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
-        d.y = (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
-        d.z = (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
-        dmean = dmean + d;
-    }
-
-    // ---- colour -> SH (+ view-direction term on the mean)
+    for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gS[i];
     if (a.shs) {
-        const V3 cam = v3(a.campos[0], a.campos[1], a.campos[2]);
-        const V3 dL_dRGB = v3(rec1.y, rec1.z, rec1.w);
-        const V3 d = sh_backward(a.D, mean, cam, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dL_dRGB,
-                                 a.dL_dsh + (size_t)idx * a.M * 3);
-        dmean = dmean + d;
+        float* out = a.dL_dsh + (size_t)idx * a.M * 3;
+        const int used = 3 * (a.D + 1) * (a.D + 1);
+#pragma unroll
+        for (int i = 0; i < SH_MAX_ROWS * 3; i++)
+            if (i < used) out[i] = gsh[i];
+        for (int i = used; i < 3 * a.M; i++) out[i] = 0.f;
     }
-    a.dL_dmean3D[3 * (size_t)idx + 0] = dmean.x;
-    a.dL_dmean3D[3 * (size_t)idx + 1] = dmean.y;
-    a.dL_dmean3D[3 * (size_t)idx + 2] = dmean.z;
 
-    // ---- cov3D -> scale, rotation (reference CR/backward.cu:278-341)
+    // ---- 3D covariance -> scale, rotation (the sum over views entered gS linearly, so this runs once)
     if (a.scales) {
         const float r = q.x, x = q.y, y = q.z, z = q.w;
-        const M3 R = quat_to_cols(r, x, y, z);
-        M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        // columns of the rotation (raw quaternion, as the forward builds it)
+        const V3 c0 = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y));
+        const V3 c1 = v3(2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x));
+        const V3 c2 = v3(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y));
         const V3 s = v3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
-        S.m[0][0] = s.x; S.m[1][1] = s.y; S.m[2][2] = s.z;
-        const M3 M = m3_mul(S, R);
-        const M3 dL_dSigma = m3_cols(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
-                                     0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
-        M3 M2;
-#pragma unroll
-        for (int cI = 0; cI < 3; cI++)
-#pragma unroll
-            for (int rI = 0; rI < 3; rI++) M2.m[cI][rI] = M.m[cI][rI] * 2.0f;
-        const M3 dL_dM = m3_mul(M2, dL_dSigma);
-        const M3 Rt = m3_transpose(R);
-        M3 dL_dMt = m3_transpose(dL_dM);
-#define COLV(A, k) v3((A).m[k][0], (A).m[k][1], (A).m[k][2])
-        a.dL_dscale[3 * (size_t)idx + 0] = dot3(COLV(Rt, 0), COLV(dL_dMt, 0));
-        a.dL_dscale[3 * (size_t)idx + 1] = dot3(COLV(Rt, 1), COLV(dL_dMt, 1));
-        a.dL_dscale[3 * (size_t)idx + 2] = dot3(COLV(Rt, 2), COLV(dL_dMt, 2));
-#undef COLV
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            dL_dMt.m[0][k] *= s.x;
-            dL_dMt.m[1][k] *= s.y;
-            dL_dMt.m[2][k] *= s.z;
-        }
-#define DM(cI, rI) dL_dMt.m[cI][rI]
+        const V3 a0 = s.x * c0, a1 = s.y * c1, a2 = s.z * c2;
+        // e_k = 2 G a_k with G the full symmetric matrix (off-diagonals of the 6-vector halved)
+        const float Gxx = gS[0], Gxy = 0.5f * gS[1], Gxz = 0.5f * gS[2], Gyy = gS[3], Gyz = 0.5f * gS[4], Gzz = gS[5];
+#define GMUL(v) v3(2.f * (Gxx * (v).x + Gxy * (v).y + Gxz * (v).z), 2.f * (Gxy * (v).x + Gyy * (v).y + Gyz * (v).z), \
+                   2.f * (Gxz * (v).x + Gyz * (v).y + Gzz * (v).z))
+        const V3 e0 = GMUL(a0), e1 = GMUL(a1), e2 = GMUL(a2);
+#undef GMUL
+        a.dL_dscale[3 * (size_t)idx + 0] = dot3(c0, e0);
+        a.dL_dscale[3 * (size_t)idx + 1] = dot3(c1, e1);
+        a.dL_dscale[3 * (size_t)idx + 2] = dot3(c2, e2);
+        // Q_ij = dL/dR_ij: column k of Q is s_k e_k
+        const V3 Q0 = s.x * e0, Q1 = s.y * e1, Q2 = s.z * e2;
+        const float Q00 = Q0.x, Q10 = Q0.y, Q20 = Q0.z, Q01 = Q1.x, Q11 = Q1.y, Q21 = Q1.z, Q02 = Q2.x, Q12 = Q2.y, Q22 = Q2.z;
         float4 dq;
-        dq.x = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
-        dq.y = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
-        dq.z = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
-        dq.w = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
-#undef DM
+        dq.x = 2 * z * (Q10 - Q01) + 2 * y * (Q02 - Q20) + 2 * x * (Q21 - Q12);
+        dq.y = 2 * y * (Q01 + Q10) + 2 * z * (Q02 + Q20) + 2 * r * (Q21 - Q12) - 4 * x * (Q11 + Q22);
+        dq.z = 2 * x * (Q01 + Q10) + 2 * r * (Q02 - Q20) + 2 * z * (Q12 + Q21) - 4 * y * (Q00 + Q22);
+        dq.w = 2 * r * (Q10 - Q01) + 2 * x * (Q02 + Q20) + 2 * y * (Q12 + Q21) - 4 * z * (Q00 + Q11);
         *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
     }
 }
 
-int launch_preprocess_backward(const Launch& L, const gsr_params& p, const GeomView& g, const int* radii,
-                               const float* grad_rec, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                               float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot)
+int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch& B, const int* radii, float* dL_dmean2D,
+                               float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                               float* dL_dscale, float* dL_drot)
 {
     PreBwdArgs a;
-    a.P = p.P; a.D = p.D; a.M = p.M;
+    a.P = p.P; a.D = p.D; a.M = p.M; a.V = B.V;
     a.tanfovx = p.tanfovx; a.tanfovy = p.tanfovy;
     a.focal_y = p.H / (2.0f * p.tanfovy);
     a.focal_x = p.W / (2.0f * p.tanfovx);
     a.scale_modifier = p.scale_modifier;
     a.means3D = p.means3D; a.shs = p.shs; a.scales = p.scales; a.rotations = p.rotations;
     a.cov3D_precomp = p.cov3D_precomp; a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
-    a.radii = radii; a.clamped = g.clamped;
-    a.grad_rec = grad_rec; a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
+    a.radii = radii; a.clamped = B.g.clamped;
+    a.grad_rec = B.g.grad_rec; a.g_stride = B.g_stride;
+    a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
     hipLaunchKernelGGL(k_preprocess_backward, dim3((p.P + 255) / 256), dim3(256), 0, L.stream, a);
     return check_launch(L, "preprocess_backward");

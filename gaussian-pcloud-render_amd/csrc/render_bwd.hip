@@ -198,7 +198,7 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
 
 struct RenderBwdArgs {
     const uint2* ranges;
-    const uint32_t* items;       // work items: tile | chunk << 20, heaviest first (binning.hip k_bwd_items)
+    const uint32_t* items;       // work items: tile | chunk << BWD_TILE_BITS, heaviest first (binning.hip k_bwd_items)
     const uint32_t* item_count;  // [1]
     const float4* ckpt;          // forward state at chunk boundaries (render_fwd.hip)
     const float* accum;          // [3N] forward accumulated colour without background
@@ -210,6 +210,8 @@ struct RenderBwdArgs {
     const uint32_t* n_contrib;
     const float* dL_dpix;
     float* grad_rec;     // [P][GRAD_REC_WORDS] accumulation records (common.hpp)
+    uint32_t V;
+    size_t g_stride, b_stride, iv_stride;
 };
 
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
@@ -218,11 +220,23 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     // XCD-aware mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of one item
     // are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the item's list slice and Splat records
     // are fetched into that L2 once instead of four times.
-    const uint32_t n_items = a.item_count[0];
+    // Batches: groups of 32 workgroups are dealt to the views round-robin (see render_fwd.hip).
+    const uint32_t group = blockIdx.x >> 5, view = group % a.V, groups_per_view = (gridDim.x >> 5) / a.V;
+    a.ranges = at_view(a.ranges, a.iv_stride, view);
+    a.items = at_view(a.items, a.iv_stride, view);
+    a.accum = at_view(a.accum, a.iv_stride, view);
+    a.final_T = at_view(a.final_T, a.iv_stride, view);
+    a.n_contrib = at_view(a.n_contrib, a.iv_stride, view);
+    a.ckpt = at_view(a.ckpt, a.b_stride, view);
+    a.point_list = at_view(a.point_list, a.b_stride, view);
+    a.splat = at_view(a.splat, a.g_stride, view);
+    a.grad_rec = at_view(a.grad_rec, a.g_stride, view);
+    a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
+    const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
     __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
-  for (uint32_t item_idx = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u); item_idx < n_items; item_idx += (gridDim.x >> 5) * 8u) {
+  for (uint32_t item_idx = (group / a.V) * 8u + (blockIdx.x & 7u); item_idx < n_items; item_idx += groups_per_view * 8u) {
     const uint32_t item = a.items[item_idx];
-    const uint32_t tile = item & 0xFFFFFu, chunk = item >> 20;
+    const uint32_t tile = item & ((1u << BWD_TILE_BITS) - 1u), chunk = item >> BWD_TILE_BITS;
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
@@ -468,29 +482,34 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
   }
 }
 
-int launch_render_backward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                           const ImageView& iv, const float4* ckpt, const float* dL_dpix, float* grad_rec)
+int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix)
 {
     RenderBwdArgs a;
-    a.ranges = iv.ranges;
-    a.items = iv.bwd_items;
-    a.item_count = iv.bwd_count;
-    a.ckpt = ckpt;
-    a.accum = iv.accum;
+    a.ranges = B.iv.ranges;
+    a.items = B.iv.bwd_items;
+    a.item_count = B.iv.bwd_count;
+    a.ckpt = B.b.ckpt;
+    a.accum = B.iv.accum;
     a.point_list = point_list;
-    a.splat = g.splat;
+    a.splat = B.g.splat;
     a.W = p.W; a.H = p.H;
     a.gridx = (p.W + TILE_X - 1) / TILE_X;
     const int gridy = (p.H + TILE_Y - 1) / TILE_Y;
     a.bg = p.bg;
-    a.final_T = iv.final_T;
-    a.n_contrib = iv.n_contrib;
+    a.final_T = B.iv.final_T;
+    a.n_contrib = B.iv.n_contrib;
     a.dL_dpix = dL_dpix;
-    a.grad_rec = grad_rec;
+    a.grad_rec = B.g.grad_rec;
     a.num_tiles = a.gridx * gridy;
-    // the number of items is only known on the device: a grid of one workgroup quartet per tile (as many wave slots as
-    // the chip has several times over) walks the item list with a stride
-    hipLaunchKernelGGL(k_render_backward, dim3((unsigned)div_up(a.num_tiles, 8) * 32u), dim3(64), 0, L.stream, a);
+    a.V = (uint32_t)B.V;
+    a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;
+    // the number of items is only known on the device: every view gets the same number of workgroup quartets, enough in
+    // total to fill the chip's wave slots several times over, and they walk the view's item list with a stride
+    int64_t groups = div_up(a.num_tiles, 8);
+    const int64_t fill = div_up(2048, B.V);        // 2048 groups x 32 single-wave workgroups = 8 waves per SIMD-slot set
+    if (groups > fill) groups = fill;
+    if (groups < 8) groups = 8;
+    hipLaunchKernelGGL(k_render_backward, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_backward");
 }
 

@@ -40,7 +40,9 @@ struct RenderArgs {
     uint32_t* n_contrib;
     uint32_t* tile_need;
     float4* ckpt;   // chunk-boundary state for the backward pass, or NULL
-    float* accum;   // [3N] accumulated colour without background (only written with ckpt)
+    float* accum;   // [3N] accumulated colour without background (written with ckpt, for quadrants that crossed a chunk boundary)
+    uint32_t V;                              // views in the batch
+    size_t g_stride, b_stride, iv_stride;    // bytes between consecutive views' arenas
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -136,8 +138,22 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
     // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
     // are fetched into that L2 once instead of four times.
-    const uint32_t order_slot = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u);
+    // Batches: groups of 32 workgroups (8 tiles x 4 quadrants) are dealt to the views round-robin, so the heaviest tiles of
+    // EVERY view are dispatched first and the batch has one tail instead of one per view.
+    const uint32_t group = blockIdx.x >> 5;
+    const uint32_t view = group % a.V;
+    const uint32_t order_slot = (group / a.V) * 8u + (blockIdx.x & 7u);
     if (order_slot >= (uint32_t)a.num_tiles) return;
+    a.ranges = at_view(a.ranges, a.iv_stride, view);
+    a.tile_order = at_view(a.tile_order, a.iv_stride, view);
+    a.final_T = at_view(a.final_T, a.iv_stride, view);
+    a.n_contrib = at_view(a.n_contrib, a.iv_stride, view);
+    a.tile_need = at_view(a.tile_need, a.iv_stride, view);
+    a.accum = at_view(a.accum, a.iv_stride, view);
+    a.point_list = at_view(a.point_list, a.b_stride, view);
+    if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
+    a.splat = at_view(a.splat, a.g_stride, view);
+    a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t tile = a.tile_order[order_slot];
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
@@ -161,6 +177,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     float C2 = 0.f;
     uint32_t last_contributor = 0;
     uint32_t stop_at = 0;  // 1-based index of the entry that terminated this pixel
+    bool crossed = false;  // this quadrant walked past a BWD_CHUNK boundary (wave-uniform)
     bool done = !inside;
     bool all_done = __all(done);
     if (!all_done) {
@@ -203,6 +220,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
             if (a.ckpt != nullptr && base != 0 && (base & (BWD_CHUNK - 1)) == 0 && (base >> BWD_CHUNK_SHIFT) < BWD_MAX_CHUNKS) {
                 const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)(base >> BWD_CHUNK_SHIFT);
                 a.ckpt[slot * 256 + q * 64 + lane] = make_float4(T, C01.x, C01.y, C2);
+                crossed = true;
             }
 
             // which of this round's 64 entries can reach alpha >= 1/255 somewhere in this quadrant?
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         a.out_color[pix] = C01.x + T * a.bg[0];
         a.out_color[N + pix] = C01.y + T * a.bg[1];
         a.out_color[2 * N + pix] = C2 + T * a.bg[2];
-        if (a.ckpt != nullptr) {
+        if (crossed) {   // only a backward slice that starts at a recorded boundary reads the final accumulated colour
             a.accum[pix] = C01.x;
             a.accum[N + pix] = C01.y;
             a.accum[2 * N + pix] = C2;
@@ -342,28 +360,30 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     }
 }
 
-int launch_render_forward(const Launch& L, const gsr_params& p, const GeomView& g, const uint32_t* point_list,
-                          const ImageView& iv, float* out_color, float4* ckpt)
+int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
+                          bool with_ckpt)
 {
     RenderArgs a;
-    a.ranges = iv.ranges;
-    a.tile_order = iv.tile_order;
+    a.ranges = B.iv.ranges;
+    a.tile_order = B.iv.tile_order;
     a.point_list = point_list;
-    a.splat = g.splat;
+    a.splat = B.g.splat;
     a.W = p.W; a.H = p.H;
     a.gridx = (p.W + TILE_X - 1) / TILE_X;
     const int gridy = (p.H + TILE_Y - 1) / TILE_Y;
     a.bg = p.bg;
     a.out_color = out_color;
-    a.final_T = iv.final_T;
-    a.n_contrib = iv.n_contrib;
-    a.tile_need = iv.tile_need;
-    a.ckpt = ckpt;
-    a.accum = iv.accum;
+    a.final_T = B.iv.final_T;
+    a.n_contrib = B.iv.n_contrib;
+    a.tile_need = B.iv.tile_need;
+    a.ckpt = with_ckpt ? B.b.ckpt : nullptr;
+    a.accum = B.iv.accum;
+    a.V = (uint32_t)B.V;
+    a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;
     const int T = a.gridx * gridy;
-    if (hipMemsetAsync(iv.tile_need, 0, (size_t)T * sizeof(uint32_t), L.stream) != hipSuccess) return GSR_ERR_HIP;
     a.num_tiles = T;
-    hipLaunchKernelGGL(k_render_forward, dim3((unsigned)div_up(T, 8) * 32u), dim3(64), 0, L.stream, a);
+    // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
+    hipLaunchKernelGGL(k_render_forward, dim3((unsigned)div_up(T, 8) * 32u * (unsigned)B.V), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_forward");
 }
 

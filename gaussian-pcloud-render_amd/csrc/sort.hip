@@ -7,6 +7,10 @@
 //   (2) pairs are emitted in that order and stably sorted by tile id only (ceil(bit/8) passes over R
 //   8-B pairs).  Stability of both steps gives exactly: tile, then depth bits, then Gaussian id.
 //
+// Every launch covers a batch of V independent sort problems (one per camera view, blockIdx.y), laid out at a fixed byte
+// stride; a problem's element count may live on the device (the tile sort's num_rendered is never read back mid-frame):
+// the grid is sized by the arena capacity and workgroups past the count leave at once.
+//
 // One pass = three launches: per-workgroup digit histogram, per-digit row scan, stable scatter.
 // The scatter ranks keys with wave64 ballots (one ballot per digit bit), reorders the workgroup's 4096
 // pairs in LDS, then writes digit runs with consecutive lanes on consecutive addresses.  The key bits
@@ -45,11 +49,32 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + inc - v;
 }
 
+struct SortView {
+    size_t stride;
+    const uint64_t* n_dev;
+    size_t n_stride;
+    int64_t cap;
+};
+__device__ __forceinline__ int64_t view_count(const SortView& sv, uint32_t view)
+{
+    if (sv.n_dev == nullptr) return sv.cap;
+    const uint64_t n = *at_view(sv.n_dev, sv.n_stride, view);
+    return n < (uint64_t)sv.cap ? (int64_t)n : sv.cap;
+}
+
 // ---- pass kernel 1: digit histogram per workgroup ------------------------------------------------
 template <typename KeyT>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restrict__ keys, int64_t n, int shift,
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restrict__ keys, SortView sv, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ hist, int nblk)
 {
+    const uint32_t view = blockIdx.y;
+    const int64_t n = view_count(sv, view);
+    keys = at_view(keys, sv.stride, view);
+    hist = at_view(hist, sv.stride, view);
+    if ((int64_t)blockIdx.x * RS_TILE >= n) {   // past the end: this workgroup's column of the count matrix is zero
+        hist[(size_t)threadIdx.x * nblk + blockIdx.x] = 0;
+        return;
+    }
     __shared__ uint32_t h[RS_WAVES][RADIX];
     for (int i = threadIdx.x; i < RS_WAVES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -81,8 +106,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
 }
 
 // ---- pass kernel 2: exclusive scan of each digit's row of workgroup counts -----------------------
-__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblk)
+__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblk,
+                                                       size_t stride)
 {
+    hist = at_view(hist, stride, blockIdx.y);
+    totals = at_view(totals, stride, blockIdx.y);
     __shared__ uint32_t tmp[4];
     uint32_t* row = hist + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
@@ -102,10 +130,19 @@ template <int BITS, typename KeyT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index
                                                               KeyT* __restrict__ keys_out,
-                                                              uint32_t* __restrict__ vals_out, int64_t n, int shift,
+                                                              uint32_t* __restrict__ vals_out, SortView sv, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ totals, int nblk)
 {
+    const uint32_t view = blockIdx.y;
+    const int64_t n = view_count(sv, view);
+    if ((int64_t)blockIdx.x * RS_TILE >= n) return;
+    keys_in = at_view(keys_in, sv.stride, view);
+    if (vals_in) vals_in = at_view(vals_in, sv.stride, view);
+    keys_out = at_view(keys_out, sv.stride, view);
+    vals_out = at_view(vals_out, sv.stride, view);
+    hist = at_view(hist, sv.stride, view);
+    totals = at_view(totals, sv.stride, view);
     __shared__ uint32_t s_key[RS_TILE];
     __shared__ uint32_t s_val[RS_TILE];
     __shared__ uint32_t wave_cnt[RS_WAVES][RADIX];  // running per-wave digit counts, then exclusive over waves
@@ -194,14 +231,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     }
 }
 
-// Sorts on key bits [0, end_bit).  key[0]/val[0] hold the input (val[0] ignored when iota_vals); the
-// result lands in key[*result_buffer] / val[*result_buffer].
-int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32_t* val[2], bool iota_vals, int end_bit,
-                            uint32_t* hist, uint32_t* totals, int* result_buffer, bool key16)
+// Sorts on key bits [0, end_bit).  job.key[0]/val[0] hold the input (val[0] ignored when iota_vals); the
+// result lands in key[*result_buffer] / val[*result_buffer] (the parity only depends on end_bit).
+int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16)
 {
     int cur = 0;
-    if (n > 0) {
-        const int nblk = (int)div_up(n, RS_TILE);
+    if (job.cap > 0 && job.V > 0) {
+        const int nblk = (int)div_up(job.cap, RS_TILE);
+        const SortView sv{job.stride, job.n_dev, job.n_stride, job.cap};
+        const dim3 grid(nblk, job.V);
         bool first = true;
         const int npass = (end_bit + RADIX_BITS - 1) / RADIX_BITS;
         int shift = 0;
@@ -209,25 +247,25 @@ int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32
             const int bits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);   // even split, wider digits first
             const uint32_t mask = (1u << bits) - 1u;
             if (key16)
-                hipLaunchKernelGGL(k_radix_hist<uint16_t>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, (const uint16_t*)key[cur], n,
-                                   shift, mask, hist, nblk);
+                hipLaunchKernelGGL(k_radix_hist<uint16_t>, grid, dim3(RS_THREADS), 0, L.stream, (const uint16_t*)job.key[cur], sv,
+                                   shift, mask, job.hist, nblk);
             else
-                hipLaunchKernelGGL(k_radix_hist<uint32_t>, dim3(nblk), dim3(RS_THREADS), 0, L.stream, (const uint32_t*)key[cur], n,
-                                   shift, mask, hist, nblk);
+                hipLaunchKernelGGL(k_radix_hist<uint32_t>, grid, dim3(RS_THREADS), 0, L.stream, (const uint32_t*)job.key[cur], sv,
+                                   shift, mask, job.hist, nblk);
             if (int e = check_launch(L, "radix_hist")) return e;
-            hipLaunchKernelGGL(k_radix_rowscan, dim3(RADIX), dim3(256), 0, L.stream, hist, totals, nblk);
+            hipLaunchKernelGGL(k_radix_rowscan, dim3(RADIX, job.V), dim3(256), 0, L.stream, job.hist, job.totals, nblk, job.stride);
             if (int e = check_launch(L, "radix_rowscan")) return e;
-            const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)val[cur];
-#define GSR_SCATTER(B)                                                                                                     \
-    case B:                                                                                                                \
-        if (key16)                                                                                                         \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t>), dim3(nblk), dim3(RS_THREADS), 0, L.stream,                  \
-                               (const uint16_t*)key[cur], vin, (uint16_t*)key[cur ^ 1], val[cur ^ 1], n, shift, mask, hist, \
-                               totals, nblk);                                                                              \
-        else                                                                                                               \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t>), dim3(nblk), dim3(RS_THREADS), 0, L.stream,                  \
-                               (const uint32_t*)key[cur], vin, key[cur ^ 1], val[cur ^ 1], n, shift, mask, hist, totals,   \
-                               nblk);                                                                                      \
+            const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)job.val[cur];
+#define GSR_SCATTER(B)                                                                                                        \
+    case B:                                                                                                                   \
+        if (key16)                                                                                                            \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t>), grid, dim3(RS_THREADS), 0, L.stream,                           \
+                               (const uint16_t*)job.key[cur], vin, (uint16_t*)job.key[cur ^ 1], job.val[cur ^ 1], sv, shift,  \
+                               mask, job.hist, job.totals, nblk);                                                             \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t>), grid, dim3(RS_THREADS), 0, L.stream,                           \
+                               (const uint32_t*)job.key[cur], vin, job.key[cur ^ 1], job.val[cur ^ 1], sv, shift, mask,       \
+                               job.hist, job.totals, nblk);                                                                   \
         break;
             switch (bits) {
                 GSR_SCATTER(1) GSR_SCATTER(2) GSR_SCATTER(3) GSR_SCATTER(4) GSR_SCATTER(5) GSR_SCATTER(6) GSR_SCATTER(7)
@@ -239,91 +277,11 @@ int launch_radix_sort_pairs(const Launch& L, int64_t n, uint32_t* key[2], uint32
             first = false;
             shift += bits;
         }
+    } else {
+        cur = ((end_bit + RADIX_BITS - 1) / RADIX_BITS) & 1;
     }
     *result_buffer = cur;
     return GSR_OK;
-}
-
-// ---- exclusive prefix sum of tiles_touched taken in depth order ------------------------------------
-// (the reference's cub::DeviceScan::InclusiveSum over index order, CR/rasterizer_impl.cu:277; the total
-// -- num_rendered -- is order independent.)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(int P, const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ tiles_touched,
-                                                              uint32_t* __restrict__ block_sums)
-{
-    __shared__ uint32_t tmp[4];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < P) s += tiles_touched[order[base + i]];
-    uint32_t tot;
-    block_exclusive_scan_256(s, tmp, &tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_scan_blocksums(uint32_t* __restrict__ block_sums, int nb,
-                                                        uint64_t* __restrict__ total_out)
-{
-    // 64-bit throughout: a hostile cloud (huge scales) can touch P x T > 2^32 tiles; the host refuses such a frame,
-    // but it has to see the true total to do so.
-    __shared__ uint64_t tmp64[4];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint64_t carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += 256) {
-        const int b = b0 + threadIdx.x;
-        const uint64_t v = b < nb ? (uint64_t)block_sums[b] : 0ull;
-        uint64_t inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc, d, 64);
-            if (lane >= (uint32_t)d) inc += n;
-        }
-        if (lane == 63) tmp64[w] = inc;
-        __syncthreads();
-        uint64_t base = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if ((uint32_t)i < w) base += tmp64[i];
-        const uint64_t tot = tmp64[0] + tmp64[1] + tmp64[2] + tmp64[3];
-        __syncthreads();
-        if (b < nb) block_sums[b] = (uint32_t)(carry + base + inc - v);  // offsets are only used when the total fits
-        carry += tot;
-    }
-    if (threadIdx.x == 0) total_out[0] = carry;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int P, const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ tiles_touched,
-                                                             const uint32_t* __restrict__ block_sums,
-                                                             uint32_t* __restrict__ dup_offset)
-{
-    __shared__ uint32_t tmp[4];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t c[SCAN_ITEMS], s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        c[i] = (base + i < P) ? tiles_touched[order[base + i]] : 0u;
-        s += c[i];
-    }
-    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan_256(s, tmp, nullptr);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < P) dup_offset[base + i] = run;
-        run += c[i];
-    }
-}
-
-int launch_offsets_scan(const Launch& L, int P, const uint32_t* order, const uint32_t* tiles_touched,
-                        uint32_t* dup_offset, uint32_t* scan_tmp, uint64_t* total_out)
-{
-    const int nb = (int)div_up(P, SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, L.stream, P, order, tiles_touched, scan_tmp);
-    if (int e = check_launch(L, "scan_reduce")) return e;
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, L.stream, scan_tmp, nb, total_out);
-    if (int e = check_launch(L, "scan_blocksums")) return e;
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, L.stream, P, order, tiles_touched, scan_tmp, dup_offset);
-    return check_launch(L, "scan_apply");
 }
 
 }  // namespace gsr

@@ -189,3 +189,76 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp,
             raster_settings,
         )
+
+
+# ---- extension: all views of one cloud in ONE submission ----------------------------------------------------
+# The reference's caller loops views in Python, one GaussianRasterizer call each (simple_raw_render.py:259-278).  The entry
+# points below take the list of per-view settings instead and hand the whole batch to the C ABI's gsr_forward_batch /
+# gsr_backward_batch: one preprocess grid over V x P, one render grid over all views' tiles, and gradients summed over the
+# views on the device -- the same numbers as V separate calls whose gradients autograd adds up.
+def _stack_views(settings_list, device):
+    s0 = settings_list[0]
+    for s in settings_list[1:]:
+        if (s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.prefiltered) != (
+                s0.image_height, s0.image_width, s0.tanfovx, s0.tanfovy, s0.scale_modifier, s0.sh_degree, s0.prefiltered) or \
+                not torch.equal(s.bg.cpu(), s0.bg.cpu()):
+            raise Exception("rasterize_views: the views of a batch must share image size, tan(fov), background, scale "
+                            "modifier, SH degree and the prefiltered flag")
+    view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+    proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+    cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
+    return view, proj, cam
+
+
+class _RasterizeGaussiansViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings_list):
+        rs = settings_list[0]
+        view, proj, cam = _stack_views(settings_list, means3D.device)
+        need_backward = any(ctx.needs_input_grad)
+        counts, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_batch(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view, proj,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, cam, rs.prefiltered,
+            any(s.debug for s in settings_list), need_backward=need_backward)
+        ctx.raster_settings = rs
+        ctx.num_rendered = counts
+        ctx.opacity_shape = tuple(opacities.shape)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+                              imgBuffer, view, proj, cam)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, view, proj,
+         cam) = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _C.rasterize_gaussians_backward_batch(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, view, proj, rs.tanfovx,
+            rs.tanfovy, grad_out_color, sh, rs.sh_degree, cam, geomBuffer, binningBuffer, imgBuffer, rs.debug)
+
+        def fit(g, inp):
+            return g if inp.numel() != 0 else None
+
+        return (grad_means3D, grad_means2D, fit(grad_sh, sh), fit(grad_colors_precomp, colors_precomp),
+                grad_opacities.reshape(ctx.opacity_shape), fit(grad_scales, scales), fit(grad_rotations, rotations),
+                fit(grad_cov3Ds_precomp, cov3Ds_precomp), None)
+
+
+def rasterize_views(means3D, means2D, opacities, settings_list, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+    """GaussianRasterizer.forward for a LIST of GaussianRasterizationSettings (views of one cloud) in one call.
+    Returns (colors [V,3,H,W], radii [V,P]); gradients of the shared inputs are the sums over the views."""
+    if len(settings_list) == 0:
+        raise Exception("rasterize_views: empty settings list")
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+    e = torch.Tensor([])
+    return _RasterizeGaussiansViews.apply(
+        means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
+        e if scales is None else scales, e if rotations is None else rotations, e if cov3D_precomp is None else cov3D_precomp,
+        list(settings_list))

@@ -30,9 +30,11 @@ class GsrParams(C.Structure):
 
 
 # every symbol include/gsr.h declares (tests check the library exports all of them)
-SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_stage1", "gsr_forward_stage2",
-           "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling", "gsr_get_profile", "gsr_last_error",
-           "gsr_version", "gsr_selftest", "gsr_forward_recolor")
+SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
+           "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
+           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor")
+
+GSR_RETRY = 1
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
          FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12)
@@ -50,6 +52,9 @@ def _load():
     lib.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
     lib.gsr_binning_bytes.restype = C.c_size_t
     lib.gsr_binning_bytes.argtypes = [C.c_int64]
+    lib.gsr_forward_batch.restype = C.c_int
+    lib.gsr_forward_batch.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
+                                      C.POINTER(C.c_int64), C.c_int, _fp]
     lib.gsr_forward_stage1.restype = C.c_int
     lib.gsr_forward_stage1.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp,
                                        C.POINTER(C.c_int64), _fp]
@@ -57,14 +62,17 @@ def _load():
     lib.gsr_forward_stage2.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
                                        C.c_int64, _fp, _fp]
     lib.gsr_forward_recolor.restype = C.c_int
-    lib.gsr_forward_recolor.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, C.c_int64, _fp, _fp]
+    lib.gsr_forward_recolor.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp]
+    lib.gsr_backward_batch.restype = C.c_int
+    lib.gsr_backward_batch.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, _fp, C.c_size_t, _fp, C.c_size_t, _fp,
+                                       C.c_size_t] + [_fp] * 9 + [_fp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_backward.argtypes = [C.POINTER(GsrParams), _fp, C.c_int64, _fp, C.c_size_t, _fp, C.c_size_t, _fp,
-                                 C.c_size_t] + [_fp] * 10 + [_fp]
+                                 C.c_size_t] + [_fp] * 9 + [_fp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _fp]
     lib.gsr_query.restype = C.c_int
-    lib.gsr_query.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, _fp, _fp, C.c_int64, _fp, C.c_size_t, _fp]
+    lib.gsr_query.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, _fp, C.c_size_t, _fp, C.c_int64, _fp, C.c_size_t, _fp]
     lib.gsr_set_profiling.restype = None
     lib.gsr_set_profiling.argtypes = [C.c_int]
     lib.gsr_get_profile.restype = C.c_int
@@ -130,88 +138,149 @@ def _params(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov
     return p, keep
 
 
+# ---- binning-arena capacity -----------------------------------------------------------------------------------------
+# The pair count of a frame (num_rendered) is only known on the device while the frame is being enqueued, so the binning
+# arena is allocated by CAPACITY: the largest count this (device, P, W, H) configuration produced recently, plus slack.
+# A frame that needs more gets GSR_RETRY and repeats its binning half with an exact-size arena; the first frame of a
+# configuration counts first (stage 1) and then binds (stage 2), like the reference's synchronous flow.
+_CAP_HINT = {}
+CAP_SLACK = 1.25
+
+
+def _cap_key(device, P, W, H):
+    return (device.index if device.index is not None else torch.cuda.current_device(), int(P), int(W), int(H))
+
+
+def _note_counts(key, counts):
+    old = _CAP_HINT.get(key, 0)
+    _CAP_HINT[key] = max(max(counts), int(old * 0.98))   # shrinks slowly when the frames get lighter
+
+
+def reset_capacity_hints():
+    _CAP_HINT.clear()
+
+
+def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                              viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                              camposs, prefiltered, debug, need_backward=True, capacity=None):
+    """V views of one cloud in one submission (C ABI gsr_forward_batch): viewmatrices / projmatrices [V,4,4] (transposed like
+    the reference's settings), camposs [V,3].  Returns (num_rendered list[V], out_color [V,3,H,W], radii [V,P],
+    geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity."""
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    device = means3D.device
+    _require_hip(device)
+    viewmatrices = viewmatrices.reshape(-1, 4, 4)
+    projmatrices = projmatrices.reshape(-1, 4, 4)
+    camposs = camposs.reshape(-1, 3)
+    V = viewmatrices.shape[0]
+    if projmatrices.shape[0] != V or camposs.shape[0] != V or V < 1:
+        raise RuntimeError("viewmatrices, projmatrices and camposs must describe the same number of views (>= 1)")
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    byte = dict(dtype=torch.uint8, device=device)
+    if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
+        e = torch.empty((0,), **byte)
+        return ([0] * V, torch.zeros((V, 3, H, W), dtype=torch.float32, device=device),
+                torch.zeros((V, 0), dtype=torch.int32, device=device), e, e.clone(), e.clone())
+    # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
+    out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((V, P), dtype=torch.int32, device=device)
+    key = _cap_key(device, P, W, H)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                          viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, prefiltered, debug,
+                          need_backward)
+        geom = torch.empty((V * lib.gsr_geom_bytes(P),), **byte)
+        img = torch.empty((V * lib.gsr_image_bytes(W, H),), **byte)
+        counts = (C.c_int64 * V)()
+        if capacity is None:
+            hint = _CAP_HINT.get(key)
+            capacity = None if hint is None else int(hint * CAP_SLACK) + 4096
+        if capacity is None and V == 1:
+            # first frame of this configuration: count, then bind (one host round trip, like the reference)
+            _check(lib.gsr_forward_stage1(C.byref(p), geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
+                                          radii.data_ptr(), counts, stream))
+            binning = torch.empty((lib.gsr_binning_bytes(int(counts[0] * CAP_SLACK) + 4096),), **byte)
+            _check(lib.gsr_forward_stage2(C.byref(p), geom.data_ptr(), geom.numel(), binning.data_ptr(), binning.numel(),
+                                          img.data_ptr(), img.numel(), counts[0], out_color.data_ptr(), stream))
+        else:
+            if capacity is None:
+                capacity = 16 * P      # first batch of this configuration: a guess, corrected by the retry below
+            binning = torch.empty((V * lib.gsr_binning_bytes(int(capacity)),), **byte)
+            rc = lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
+                                       binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, 0,
+                                       stream)
+            if rc == GSR_RETRY:
+                need = int(max(counts) * CAP_SLACK) + 4096
+                binning = torch.empty((V * lib.gsr_binning_bytes(need),), **byte)
+                rc = lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
+                                           binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts,
+                                           1, stream)
+            _check(rc)
+    del keep
+    counts = [int(c) for c in counts]
+    _note_counts(key, counts)
+    return counts, out_color, radii, geom, binning, img
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, need_backward=True):
     """Counterpart of RasterizeGaussiansCUDA (rasterize_points.cu:35-115); same argument order, same
     6-tuple result (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer)."""
-    if means3D.dim() != 2 or means3D.shape[1] != 3:
-        raise RuntimeError("means3D must have dimensions (num_points, 3)")
-    device = means3D.device
-    _require_hip(device)
-    P, H, W = means3D.shape[0], int(image_height), int(image_width)
-    byte = dict(dtype=torch.uint8, device=device)
-    if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
-        e = torch.empty((0,), **byte)
-        return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
-                e, e.clone(), e.clone())
-    # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
-    out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-    radii = torch.empty((P,), dtype=torch.int32, device=device)
-    with torch.cuda.device(device):
-        stream = torch.cuda.current_stream(device).cuda_stream
-        p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                          viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug,
-                          need_backward)
-        geom = torch.empty((lib.gsr_geom_bytes(P),), **byte)
-        img = torch.empty((lib.gsr_image_bytes(W, H),), **byte)
-        R = C.c_int64(0)
-        _check(lib.gsr_forward_stage1(C.byref(p), geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
-                                      radii.data_ptr(), C.byref(R), stream))
-        binning = torch.empty((lib.gsr_binning_bytes(R.value),), **byte)
-        _check(lib.gsr_forward_stage2(C.byref(p), geom.data_ptr(), geom.numel(), binning.data_ptr(), binning.numel(),
-                                      img.data_ptr(), img.numel(), R.value, out_color.data_ptr(), stream))
-    del keep
-    return int(R.value), out_color, radii, geom, binning, img
+    counts, out_color, radii, geom, binning, img = rasterize_gaussians_batch(
+        background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+        tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, need_backward=need_backward)
+    return counts[0], out_color[0], radii[0], geom, binning, img
 
 
 def recolor(background, means3D, colors, sh, degree, campos, image_height, image_width, num_rendered, geomBuffer,
             binningBuffer, imgBuffer, debug=False):
-    """Re-render a finished forward's view with other per-Gaussian colours (exactly one of `colors` [P,3] / `sh`
-    [P,M,3] non-empty), reusing its geometry, sorted lists and ranges (gsr_forward_recolor).  Returns color [3,H,W]."""
+    """Re-render a finished forward's view(s) with other per-Gaussian colours (exactly one of `colors` [P,3] / `sh`
+    [P,M,3] non-empty), reusing its geometry, sorted lists and ranges (gsr_forward_recolor).  campos [3] -> color [3,H,W];
+    campos [V,3] (a batch forward's arenas) -> [V,3,H,W]."""
     device = means3D.device
     _require_hip(device)
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
-    if P == 0:
-        return out_color
-    with torch.cuda.device(device):
-        e = torch.empty(0)
-        p, keep = _params(background, means3D, colors, torch.empty((1,), device=device), e, e, 1.0, e,
-                          torch.empty((1,), device=device), torch.empty((1,), device=device), 1.0, 1.0, H, W, sh, degree,
-                          campos, False, debug, False)
-        _check(lib.gsr_forward_recolor(C.byref(p), geomBuffer.data_ptr(), geomBuffer.numel(), binningBuffer.data_ptr(),
-                                       binningBuffer.numel(), imgBuffer.data_ptr(), imgBuffer.numel(), int(num_rendered),
-                                       out_color.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
-        del keep
-    return out_color
+    single = campos.numel() == 3
+    V = 1 if single else campos.reshape(-1, 3).shape[0]
+    out_color = torch.zeros((V, 3, H, W), dtype=torch.float32, device=device)
+    if P != 0:
+        with torch.cuda.device(device):
+            e = torch.empty(0)
+            p, keep = _params(background, means3D, colors, torch.empty((1,), device=device), e, e, 1.0, e,
+                              torch.empty((1,), device=device), torch.empty((1,), device=device), 1.0, 1.0, H, W, sh, degree,
+                              campos, False, debug, False)
+            _check(lib.gsr_forward_recolor(C.byref(p), V, geomBuffer.data_ptr(), geomBuffer.numel(), binningBuffer.data_ptr(),
+                                           binningBuffer.numel(), imgBuffer.data_ptr(), imgBuffer.numel(),
+                                           out_color.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+            del keep
+    return out_color[0] if single else out_color
 
 
-def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
-                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """Counterpart of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); same argument order,
-    same 8-tuple (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                       viewmatrices, projmatrices, tan_fovx, tan_fovy, dL_dout_color, sh, degree, camposs,
+                                       geomBuffer, binningBuffer, imageBuffer, debug):
+    """Backward of rasterize_gaussians_batch: dL_dout_color [V,3,H,W], radii [V,P]; gradients summed over the views.
+    Returns the reference's 8-tuple (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+    dL_drotations)."""
     device = means3D.device
     _require_hip(device)
     P = means3D.shape[0]
-    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    V, H, W = int(dL_dout_color.shape[0]), int(dL_dout_color.shape[2]), int(dL_dout_color.shape[3])
     M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0
     z = dict(dtype=torch.float32, device=device)
-    # Cleared by the caller (include/gsr.h): the [P,16] accumulation records of the render backward and dL_dsh (unused
-    # rows stay zero) -- slices of ONE zero-filled allocation, so the clearing is one fill kernel.  Everything else is
-    # written for every Gaussian by the per-Gaussian backward kernel.
+    # Nothing is cleared here: the per-Gaussian backward kernel writes every output for every Gaussian (the reference
+    # zero-fills nine tensors, rasterize_points.cu:151-159), and the accumulation records live in the geometry arena.
     has_sr = scales.numel() != 0 and P != 0
-    n_rec = 16 * P
-    flat = torch.zeros((n_rec + 3 * M * P,), **z)
-    grad_rec = flat[:n_rec]
-    dL_dsh = flat[n_rec:].view(P, M, 3)
     e_or_z = torch.empty if P != 0 else torch.zeros
     dL_dmeans2D = e_or_z((P, 3), **z)
     dL_dcolors = e_or_z((P, 3), **z)
     dL_dopacity = e_or_z((P, 1), **z)
     dL_dmeans3D = e_or_z((P, 3), **z)
     dL_dcov3D = e_or_z((P, 6), **z)
+    dL_dsh = e_or_z((P, M, 3), **z)
     dL_dscales = torch.empty((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
     dL_drotations = torch.empty((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
@@ -219,18 +288,29 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             stream = torch.cuda.current_stream(device).cuda_stream
             opacity_unused = torch.empty((1,), **z)  # opacity lives in the geom arena; pointer only has to be non-NULL
             p, keep = _params(background, means3D, colors, opacity_unused, scales, rotations, scale_modifier,
-                              cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False,
+                              cov3D_precomp, viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, False,
                               debug, True)
             dpix = _f32c(dL_dout_color, device, "dL_dout_color")
             radii_c = radii.contiguous()
-            _check(lib.gsr_backward(C.byref(p), radii_c.data_ptr(), int(R), geomBuffer.data_ptr(), geomBuffer.numel(),
-                                    binningBuffer.data_ptr(), binningBuffer.numel(), imageBuffer.data_ptr(),
-                                    imageBuffer.numel(), dpix.data_ptr(), dL_dmeans2D.data_ptr(), grad_rec.data_ptr(),
-                                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
-                                    dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                                    stream))
+            _check(lib.gsr_backward_batch(C.byref(p), V, radii_c.data_ptr(), geomBuffer.data_ptr(), geomBuffer.numel(),
+                                          binningBuffer.data_ptr(), binningBuffer.numel(), imageBuffer.data_ptr(),
+                                          imageBuffer.numel(), dpix.data_ptr(), dL_dmeans2D.data_ptr(),
+                                          dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
+                                          dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
+                                          stream))
             del keep
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """Counterpart of RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196); same argument order,
+    same 8-tuple (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    return rasterize_gaussians_backward_batch(
+        background, means3D, radii.reshape(1, -1), colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, dL_dout_color.reshape((1,) + tuple(dL_dout_color.shape[-3:])), sh, degree, campos,
+        geomBuffer, binningBuffer, imageBuffer, debug)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
@@ -270,8 +350,8 @@ def query(name, P, W, H, R, geom, binning, img):
     p = GsrParams()
     p.P, p.W, p.H = P, W, H
     with torch.cuda.device(geom.device):
-        _check(lib.gsr_query(C.byref(p), Q[name], geom.data_ptr(), _ptr(binning), img.data_ptr(), int(R), out.data_ptr(),
-                             out.numel() * out.element_size(), torch.cuda.current_stream(geom.device).cuda_stream))
+        _check(lib.gsr_query(C.byref(p), Q[name], geom.data_ptr(), _ptr(binning), binning.numel(), img.data_ptr(), int(R),
+                             out.data_ptr(), out.numel() * out.element_size(), torch.cuda.current_stream(geom.device).cuda_stream))
     return out
 
 
@@ -285,7 +365,7 @@ def set_profiling(on):
 
 
 def get_profile():
-    names = (C.c_char_p * 256)()
-    ms = (C.c_float * 256)()
-    n = lib.gsr_get_profile(names, ms, 256)
+    names = (C.c_char_p * 8192)()
+    ms = (C.c_float * 8192)()
+    n = lib.gsr_get_profile(names, ms, 8192)
     return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -26,11 +26,18 @@
  *   - optional inputs are NULL when absent (the reference passes data_ptr() of empty tensors, i.e.
  *     nullptr: rasterizer_impl.cu:321,389,411).
  *   - every launch goes to the explicit `stream` (the reference uses the legacy default stream).
- *   - the binning arena size depends on num_rendered, which is only known after preprocess + scan,
- *     hence two forward stages (the reference grows its arena through a std::function callback after
- *     the same device->host read-back, rasterizer_impl.cu:279-285).
- *   - return value: 0 = ok, negative = error (text via gsr_last_error()).  With debug != 0 the
- *     library synchronises and checks after every kernel like CHECK_CUDA(…, true).
+ *   - the binning arena size depends on num_rendered, which the reference reads back in the middle of
+ *     the frame to grow its arena through a std::function callback (rasterizer_impl.cu:279-285).  Here
+ *     the count stays on the device: the caller hands over an arena of some CAPACITY (gsr_binning_bytes
+ *     of the pair count it expects, e.g. the previous frame's plus slack), the whole frame is enqueued
+ *     without a host round trip, and gsr_forward_batch reports afterwards whether the capacity was enough
+ *     (GSR_RETRY: allocate gsr_binning_bytes(max num_rendered) and repeat with resume = 1).  The
+ *     two-stage pair gsr_forward_stage1/_stage2 keeps the reference's synchronous shape on top of that.
+ *   - a call covers a batch of V camera views of ONE cloud (V = 1: the reference's per-view call).
+ *     Per-view inputs (viewmatrix, projmatrix, campos) and outputs (radii, out_color, dL_dpix) are V
+ *     consecutive arrays; each scratch arena is V times the single-view size.
+ *   - return value: 0 = ok, negative = error (text via gsr_last_error()), GSR_RETRY = see above.  With
+ *     debug != 0 the library synchronises and checks after every kernel like CHECK_CUDA(…, true).
  */
 #ifndef GSR_H
 #define GSR_H
@@ -47,6 +54,7 @@ extern "C" {
 #define GSR_ERR_HIP (-2)      /* a HIP call or kernel failed                                    */
 #define GSR_ERR_CAPACITY (-3) /* an arena is smaller than gsr_*_bytes() requires                */
 #define GSR_ERR_TRAP (-4)     /* prefiltered=1 but a point was culled (auxiliary.h:156-160)     */
+#define GSR_RETRY 1           /* forward: a view produced more pairs than the binning arena holds */
 
 typedef void* gsr_stream_t; /* hipStream_t */
 
@@ -72,49 +80,66 @@ typedef struct gsr_params {
     const float* scales;         /* [P,3]      device or NULL */
     const float* rotations;      /* [P,4]      device or NULL */
     const float* cov3D_precomp;  /* [P,6]      device or NULL */
-    const float* viewmatrix;     /* [16] column-major when flattened (auxiliary.h:58-76) device */
-    const float* projmatrix;     /* [16]       device */
-    const float* campos;         /* [3]        device */
+    const float* viewmatrix;     /* [V][16] column-major when flattened (auxiliary.h:58-76) device */
+    const float* projmatrix;     /* [V][16]    device */
+    const float* campos;         /* [V][3]     device */
 } gsr_params;
 
-/* Scratch arena sizes in bytes (256-B aligned sub-arrays inside). */
+/* Scratch arena sizes in bytes for ONE view (256-B aligned sub-arrays inside); a batch of V views needs V times as much.
+ * gsr_binning_bytes(n) is an arena that holds n pairs per view: the library derives the capacity from the arena's size. */
 size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int64_t num_rendered);
 
-/* Forward, stage 1: per-Gaussian preprocess (cull, EWA projection, SH colour), depth ordering of the
- * Gaussians, prefix sum of touched-tile counts.  Writes radii[P]; returns num_rendered through
- * *num_rendered_out after one 8-byte device->host read-back on `stream` (the only host sync of a
- * frame, cf. rasterizer_impl.cu:281).  out_color is not touched. */
+/* Forward of V views in one submission (rasterize_points.cu:35-115 / Rasterizer::forward rasterizer.h:35-59, looped over
+ * views by the reference's caller, simple_raw_render.py:259-278): per-Gaussian preprocess (cull, EWA projection, SH colour),
+ * depth ordering, (tile, Gaussian) pair emission in depth order with its prefix sum, stable radix sort by tile, tile
+ * ranges, per-tile front-to-back alpha compositing.  Writes radii[V,P], out_color[V,3,H,W] (planar CHW per view) and
+ * num_rendered[V] (HOST array).  Nothing on the host waits for the device until every kernel of the batch is enqueued.
+ * Returns GSR_OK, or GSR_RETRY when some num_rendered[v] exceeds the per-view capacity of `binning`: out_color is then
+ * invalid; call again with resume = 1, the same geom / image arenas and a binning arena of at least
+ * V * gsr_binning_bytes(max_v num_rendered[v]) bytes (only the binning half of the frame is repeated). */
+int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
+                      void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered,
+                      int resume, gsr_stream_t stream);
+
+/* The reference's synchronous shape for one view.  Stage 1: preprocess, depth ordering, pair counting; returns
+ * num_rendered through *num_rendered_out after a device->host read-back on `stream` (cf. rasterizer_impl.cu:281).
+ * out_color is not touched. */
 int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
                        int* radii, int64_t* num_rendered_out, gsr_stream_t stream);
 
-/* Forward, stage 2: (tile, Gaussian) pair emission in depth order, stable radix sort by tile, tile
- * ranges, per-tile front-to-back alpha compositing.  Writes out_color[3,H,W] (planar CHW). */
+/* Stage 2: pair emission, sort, ranges, compositing into out_color[3,H,W], with a binning arena of at least
+ * gsr_binning_bytes(num_rendered) bytes. */
 int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
                        void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
 
 /* Colour-only re-render.  The reference's caller renders four passes per view that differ only in the
  * per-Gaussian colour (world xyz / SH colour / ones / normals, simple_raw_render.py:410-524), each through the whole
- * pipeline.  After a forward (stage1 + stage2) this entry re-renders the same view with other colours on the SAME
- * geometry, lists and ranges: p->colors_precomp [P,3] (verbatim) or p->shs (evaluated like the forward does); only
- * P, D, M, W, H, bg, means3D, shs / colors_precomp, campos of *p are read.  The result is bit-identical to a full
- * forward with those colours.  The arenas stay valid for further recolor calls; a backward afterwards differentiates
- * the LAST colours rendered. */
-int gsr_forward_recolor(const gsr_params* p, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
-                        void* image, size_t image_bytes, int64_t num_rendered, float* out_color, gsr_stream_t stream);
+ * pipeline.  After a forward this entry re-renders the same V views with other colours on the SAME geometry, lists and
+ * ranges: p->colors_precomp [P,3] (verbatim) or p->shs (evaluated like the forward does); only P, D, M, W, H, bg, means3D,
+ * shs / colors_precomp, campos of *p are read.  The result is bit-identical to a full forward with those colours.  The
+ * arenas stay valid for further recolor calls; a backward afterwards differentiates the LAST colours rendered. */
+int gsr_forward_recolor(const gsr_params* p, int V, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                        void* image, size_t image_bytes, float* out_color, gsr_stream_t stream);
 
-/* Backward.  The reference zero-fills all dL_* outputs (rasterize_points.cu:151-159) and accumulates into them with
- * float atomics.  Here the render-level sums are accumulated in `grad_rec`, [P][16] floats that the CALLER ZERO-FILLS: one
- * 64-byte record per Gaussian (mean2D.xy, conic.xyw, colour rgb, opacity; the reference's internal dL_dconic tensor lives
- * in it), so that the nine atomics of a (pixel block, Gaussian) pair fall into one cache line.  Every other output is
- * written for every Gaussian (zeros for invisible ones) and needs no clearing, except dL_dsh, of which only (D+1)^2 rows
- * are written (caller zero-fills), and dL_dscale / dL_drot, which are not touched when cov3D_precomp is given.
- * shapes: dL_dmean2D[P,3] grad_rec[P,16] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3]
+/* Backward of a batch (rasterize_points.cu:117-196 / Rasterizer::backward rasterizer.h:61-90).  dL_dpix is [V,3,H,W]; the
+ * per-Gaussian gradients are SUMMED over the V views (what autograd does with the reference's per-view calls on a shared
+ * cloud).  Every output is written for every Gaussian (zeros where it is invisible; all M rows of dL_dsh), so nothing has
+ * to be cleared by the caller -- the reference zero-fills nine tensors per call (rasterize_points.cu:151-159) -- except
+ * dL_dscale / dL_drot, which are not touched when cov3D_precomp is given.  The reference's internal dL_dconic accumulator
+ * lives in the geometry arena.  Valid after a forward with need_backward = 1 on the same arenas.
+ * shapes: radii[V,P] dL_dmean2D[P,3] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3]
  * dL_dscale[P,3] dL_drot[P,4]. */
+int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void* geom, size_t geom_bytes, const void* binning,
+                       size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
+                       float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, gsr_stream_t stream);
+
+/* One view, the reference's argument shape (num_rendered is not needed: the lists' extent lives in the arenas). */
 int gsr_backward(const gsr_params* p, const int* radii, int64_t num_rendered, const void* geom, size_t geom_bytes,
                  const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
-                 const float* dL_dpix /* [3,H,W] */, float* dL_dmean2D, float* grad_rec, float* dL_dopacity,
+                 const float* dL_dpix /* [3,H,W] */, float* dL_dmean2D, float* dL_dopacity,
                  float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                  float* dL_drot, gsr_stream_t stream);
 
@@ -122,8 +147,9 @@ int gsr_backward(const gsr_params* p, const int* radii, int64_t num_rendered, co
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, gsr_stream_t stream);
 
-/* Inspection of the private arenas, for parity tests and the roofline report only (device->device
- * copies into caller buffers; not part of the hot path).  `what` is one of GSR_Q_*. */
+/* Inspection of the private arenas (view 0 of a batch; pass a view's sub-arena pointers for the others), for parity tests
+ * and the roofline report only (device->device copies into caller buffers; not part of the hot path).  `what` is one of
+ * GSR_Q_*. */
 #define GSR_Q_DEPTHS 1         /* float  [P]    view-space z of visible Gaussians (0 otherwise)            */
 #define GSR_Q_MEANS2D 2        /* float  [P,2]                                                              */
 #define GSR_Q_CONIC_OPACITY 3  /* float  [P,4]                                                              */
@@ -136,12 +162,12 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 #define GSR_Q_N_CONTRIB 10     /* uint32 [H*W]                                                              */
 #define GSR_Q_TILE_NEED 12     /* uint32 [T]   list entries the tile's render actually walked (roofline model)    */
 #define GSR_Q_CLAMPED 11       /* uint8  [P,3]                                                              */
-int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, const void* image,
+int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, size_t binning_bytes, const void* image,
               int64_t num_rendered, void* dst, size_t dst_bytes, gsr_stream_t stream);
 
-/* Per-kernel timing of the last calls on this thread (ms, hipEvent on `stream`), filled only when
- * gsr_set_profiling(1) was called.  names/ms hold up to `cap` entries; returns the count and
- * resets the record. */
+/* Per-stage timing of the calls made since gsr_set_profiling(1) (ms, hipEvents on each call's launch stream; the switch is
+ * process wide, the records are kept per stream and returned stream by stream).  names/ms hold up to `cap` entries;
+ * returns the count and resets the records. */
 void gsr_set_profiling(int on);
 int gsr_get_profile(const char** names, float* ms, int cap);
 

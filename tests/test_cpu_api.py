@@ -32,8 +32,9 @@ def test_arena_size_queries():
         b = lib.gsr_geom_bytes(P)
         assert b >= prev and b % 256 == 0
         prev = b
-    # SoA arena: 48-B splat + keys/ids/offsets/rect per Gaussian -> ~81 B/Gaussian + per-workgroup histograms
-    assert 70 * 800_000 < lib.gsr_geom_bytes(800_000) < 100 * 800_000
+    # SoA arena: 64-B splat line + 64-B gradient record + keys/ids/rect per Gaussian -> ~157 B/Gaussian + per-workgroup
+    # histograms and prefix-sum status words
+    assert 150 * 800_000 < lib.gsr_geom_bytes(800_000) < 165 * 800_000
     # binning: two key + two u32 id buffers (16 B/pair) + the backward pass's chunk-boundary state (4 KB per 1024
     # pairs = 4 B/pair); the reference needs 24 B/pair + CUB temp
     assert 20 * 11_500_000 <= lib.gsr_binning_bytes(11_500_000) < 21 * 11_500_000
@@ -119,3 +120,37 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert rc == 0 and R.value == 0
     assert N.lib.gsr_mark_visible(-1, None, None, None, None, None) == -1
     assert N.lib.gsr_mark_visible(0, None, None, None, None, None) == 0
+
+
+def test_forward_batch_rejects_bad_arguments_without_a_gpu():
+    from diff_gaussian_rasterization import _native as N
+    p = N.GsrParams()
+    p.P, p.W, p.H = 10, 8, 8
+    cnt = (ctypes.c_int64 * 4)()
+    rc = N.lib.gsr_forward_batch(ctypes.byref(p), 0, None, 0, None, 0, None, 0, None, None, cnt, 0, None)
+    assert rc == -1 and b"view count" in N.lib.gsr_last_error()
+    rc = N.lib.gsr_forward_batch(ctypes.byref(p), 4, None, 0, None, 0, None, 0, None, None, cnt, 0, None)
+    assert rc == -1 and b"required input pointer is NULL" in N.lib.gsr_last_error()
+    p.P = 0
+    cnt[2] = 7
+    rc = N.lib.gsr_forward_batch(ctypes.byref(p), 4, None, 0, None, 0, None, 0, None, None, cnt, 0, None)
+    assert rc == 0 and list(cnt) == [0, 0, 0, 0]
+    # an image with more than 2^28 tiles cannot be described by the backward's work items
+    p.P, p.W, p.H = 10, 16 * 20000, 16 * 20000
+    rc = N.lib.gsr_forward_batch(ctypes.byref(p), 1, None, 0, None, 0, None, 0, None, None, cnt, 0, None)
+    assert rc == -1
+
+
+def test_rasterize_views_validates_like_the_reference():
+    import diff_gaussian_rasterization as d
+    m = torch.zeros(2, 3)
+    st = _settings()
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        d.rasterize_views(m, m, m[:, :1], [st, st])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        d.rasterize_views(m, m, m[:, :1], [st], colors_precomp=m, scales=m)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        d.rasterize_views(m, m, m[:, :1], [st, st], colors_precomp=m, scales=m, rotations=torch.zeros(2, 4))
+    st2 = st._replace(image_width=16)
+    with pytest.raises(Exception, match="must share image size"):
+        d.rasterize_views(m, m, m[:, :1], [st, st2], colors_precomp=m, scales=m, rotations=torch.zeros(2, 4))

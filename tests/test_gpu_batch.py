@@ -1,0 +1,164 @@
+"""GPU tests (-m gpu) of the view-batched entry points (C ABI gsr_forward_batch / gsr_backward_batch) and of the
+capacity-based binning arena (no host round trip inside a frame; GSR_RETRY when the arena is too small):
+
+  * a batch of V views against V oracle forwards / backwards (gradients: the sum over views);
+  * bit-identical images / radii / pair counts between a batch and V single-view calls;
+  * the retry path: a forward started with a far too small arena still returns the right image;
+  * the autograd extension rasterize_views against V GaussianRasterizer calls.
+"""
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import check_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _views_scene(n_views=3, P=12000, W=208, H=176, profile="training"):
+    """One cloud, n_views circle cameras (view 0 is axis aligned: depth ties on the voxelised cloud)."""
+    from pcrender import camera, synth
+    cloud = synth.make_cloud("synth-THuman-256", seed=0, P=P)
+    g = synth.make_gaussians(cloud, profile=profile, seed=1)
+    views = camera.circle_views(12, fov_deg=45.0, width_px=W, height_px=H)
+    pick = [0, 1, 5, 7, 10][:n_views]
+    return g, [views[i] for i in pick], W, H
+
+
+def _batch_args(g, views, W, H, dev, bg=(1, 1, 1)):
+    e = torch.empty(0)
+    vm = torch.stack([v["viewmatrix"] for v in views]).to(dev)
+    pm = torch.stack([v["projmatrix"] for v in views]).to(dev)
+    cp = torch.stack([v["campos"] for v in views]).to(dev)
+    return (_t(np.asarray(bg, np.float32), dev), _t(g["means3D"], dev), e, _t(g["opacities"], dev), _t(g["scales"], dev),
+            _t(g["rotations"], dev), 1.0, e, vm, pm, views[0]["tanfovx"], views[0]["tanfovy"], H, W, _t(g["shs"], dev),
+            g["sh_degree"], cp, False, False)
+
+
+def test_batch_forward_backward_vs_oracle(oracle, gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(3)
+    args = _batch_args(g, views, W, H, dev)
+    counts, color, radii, geom, binning, img = N.rasterize_gaussians_batch(*args, need_backward=True)
+    V = len(views)
+    assert color.shape == (V, 3, H, W) and radii.shape == (V, g["means3D"].shape[0])
+    rng = np.random.default_rng(9)
+    dL = rng.uniform(-1, 1, (V, 3, H, W)).astype(np.float32)
+    grads = N.rasterize_gaussians_backward_batch(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9],
+                                                 args[10], args[11], _t(dL, dev), args[14], args[15], args[16], geom, binning, img, False)
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+    gp = {n: x.cpu().numpy() for n, x in zip(names, grads)}
+    total = None
+    flips = False
+    for v, view in enumerate(views):
+        s = util.scene_from(g, view, W, H, bg=(1, 1, 1))
+        o, go = oracle.forward_backward(s, dL[v])
+        assert counts[v] == o["R"]
+        np.testing.assert_array_equal(radii[v].cpu().numpy(), o["radii"])
+        err = np.abs(color[v].cpu().numpy() - o["out_color"]).max(axis=0)
+        assert (err > 1e-4).mean() <= 2e-3
+        flips = flips or bool((err > 1e-4).any())
+        go["dL_dopacity"] = go["dL_dopacity"].reshape(-1, 1)
+        total = go if total is None else {k: total[k] + go[k] for k in total}
+    if not flips:
+        check_grads(gp, total, "batch of %d views vs summed oracle gradients" % V)
+
+
+def test_batch_equals_single_view_calls_bit_for_bit(gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(5, P=20000, W=320, H=240)
+    args = _batch_args(g, views, W, H, dev)
+    counts, color, radii, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)
+    for v, view in enumerate(views):
+        one = list(args)
+        one[8], one[9], one[16] = args[8][v], args[9][v], args[16][v]
+        R, c1, r1, *_ = N.rasterize_gaussians(*one, need_backward=False)
+        assert R == counts[v]
+        assert torch.equal(c1, color[v]) and torch.equal(r1, radii[v])
+
+
+def test_too_small_arena_is_retried_transparently(gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(2, P=15000)
+    args = _batch_args(g, views, W, H, dev)
+    counts_ok, color_ok, radii_ok, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)
+    assert min(counts_ok) > 20000
+    # 1000 pairs per view: every view overflows; the C ABI reports GSR_RETRY and the binding repeats the binning half
+    counts, color, radii, geom, binning, img = N.rasterize_gaussians_batch(*args, need_backward=True, capacity=1000)
+    assert counts == counts_ok and torch.equal(color, color_ok) and torch.equal(radii, radii_ok)
+    # the raw status code, and the arenas of a retried forward serve the backward
+    p, keep = N._params(*args, need_backward=False)
+    import ctypes as C
+    small = torch.empty((2 * N.lib.gsr_binning_bytes(1000),), dtype=torch.uint8, device=dev)
+    cnt = (C.c_int64 * 2)()
+    out = torch.empty_like(color)
+    rad = torch.empty_like(radii)
+    g2 = torch.empty_like(geom)
+    i2 = torch.empty_like(img)
+    with torch.cuda.device(dev):
+        rc = N.lib.gsr_forward_batch(C.byref(p), 2, g2.data_ptr(), g2.numel(), i2.data_ptr(), i2.numel(), small.data_ptr(), small.numel(),
+                                     rad.data_ptr(), out.data_ptr(), cnt, 0, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == N.GSR_RETRY and list(cnt) == counts_ok and b"resume" in N.lib.gsr_last_error()
+    dL = torch.ones_like(color)
+    grads = N.rasterize_gaussians_backward_batch(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9],
+                                                 args[10], args[11], dL, args[14], args[15], args[16], geom, binning, img, False)
+    assert all(torch.isfinite(x).all() for x in grads) and float(grads[3].abs().max()) > 0
+
+
+def test_rasterize_views_autograd_vs_per_view_calls(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
+    dev = gpu_device
+    g, views, W, H = _views_scene(4, P=10000, W=160, H=144)
+    bg = torch.ones(3, device=dev)
+    sts = [GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=v["tanfovx"], tanfovy=v["tanfovy"], bg=bg,
+                                         scale_modifier=1.0, viewmatrix=v["viewmatrix"].to(dev), projmatrix=v["projmatrix"].to(dev),
+                                         sh_degree=g["sh_degree"], campos=v["campos"].to(dev), prefiltered=False, debug=False)
+           for v in views]
+    G = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (len(views), 3, H, W)).astype(np.float32)).to(dev)
+
+    def leaves():
+        L = {k: _t(g[k], dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        L["means2D"] = torch.zeros_like(L["means3D"], requires_grad=True)
+        return L
+
+    A = leaves()
+    imgs, radii = rasterize_views(A["means3D"], A["means2D"], A["opacities"], sts, shs=A["shs"], scales=A["scales"], rotations=A["rotations"])
+    (imgs * G).sum().backward()
+    B = leaves()
+    loss = 0
+    for v, st in enumerate(sts):
+        im, rd = GaussianRasterizer(st)(means3D=B["means3D"], means2D=B["means2D"], shs=B["shs"], opacities=B["opacities"],
+                                        scales=B["scales"], rotations=B["rotations"])
+        assert torch.equal(im, imgs[v]) and torch.equal(rd, radii[v])
+        loss = loss + (im * G[v]).sum()
+    loss.backward()
+    gp = dict(dL_dmean2D=A["means2D"].grad, dL_dopacity=A["opacities"].grad, dL_dmean3D=A["means3D"].grad, dL_dsh=A["shs"].grad,
+              dL_dscale=A["scales"].grad, dL_drot=A["rotations"].grad)
+    go = dict(dL_dmean2D=B["means2D"].grad, dL_dopacity=B["opacities"].grad, dL_dmean3D=B["means3D"].grad, dL_dsh=B["shs"].grad,
+              dL_dscale=B["scales"].grad, dL_drot=B["rotations"].grad)
+    check_grads({k: x.cpu().numpy() for k, x in gp.items()}, {k: x.cpu().numpy() for k, x in go.items()}, "rasterize_views",
+                names=tuple(gp))
+
+
+def test_no_host_sync_between_kernels_of_a_frame(gpu_device):
+    """The frame is enqueued without waiting for the device: with the stream blocked behind a long-running kernel, the
+    forward call must still return only after its own final wait, and a second frame's capacity comes from the first's."""
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(1, P=8000)
+    args = _batch_args(g, views, W, H, dev)
+    N.reset_capacity_hints()
+    c1, img1, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)      # first frame: count, then bind
+    key = N._cap_key(dev, 8000, W, H)
+    assert N._CAP_HINT[key] == c1[0]
+    c2, img2, _, _, binning, _ = N.rasterize_gaussians_batch(*args, need_backward=False)   # second: one submission
+    assert c2 == c1 and torch.equal(img1, img2)
+    assert binning.numel() >= N.lib.gsr_binning_bytes(int(c1[0] * N.CAP_SLACK))

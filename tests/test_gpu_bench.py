@@ -27,6 +27,7 @@ def test_single_rank_line_has_the_contract_fields(gpu_device):
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["value"] > 0 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["repeats"] == 5 and len(d["ms_per_step_blocks"]) == 5 and "one_core" in d["cpu_baseline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
 
@@ -39,3 +40,44 @@ def test_two_ranks_complete(gpu_device):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
+
+
+def test_rccl_backend_runs_at_world_1(gpu_device):
+    """The `nccl` (RCCL) backend itself, which the gloo stand-in above never touches: one rank, device tensors, the sharded
+    render + frame gather + gradient all-reduce of pcrender.multiview."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py"), "29543"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_bench_under_torchrun_one_rank_uses_rccl(gpu_device):
+    """bench.py launched the way the driver launches it for N > 1, with N = 1: process group on `nccl`, frames gathered
+    through RCCL, timing reduced with an RCCL all-reduce."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29542", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--repeats", "2"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "RCCL frame gather" in d["config"]["workload"] and d["repeats"] == 2
+
+
+def test_gpus_flag_launches_ranks_or_fails_loudly(gpu_device):
+    """`python bench.py --gpus 2` without torch.distributed.run: runs two RCCL ranks when the box has two GPUs, otherwise
+    refuses with a message (it must never quietly run one rank and print n_gpus: 1)."""
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--repeats", "1"] + SMALL,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert _last_json(r.stdout)["n_gpus"] == 2
+    else:
+        assert r.returncode != 0 and "only 1 GPU(s) visible" in (r.stdout + r.stderr)
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpus_flag_self_launch_two_ranks_on_one_gpu_via_gloo(gpu_device):
+    """The self-launch path end to end on a one-GPU box: --gpus 2 with the gloo stand-in and both ranks on device 0."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device-index", "0",
+                        "--no-cpu-baseline", "--repeats", "1"] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert _last_json(r.stdout)["n_gpus"] == 2

@@ -1,0 +1,280 @@
+"""GPU tests (-m gpu) for the BASELINE.json configs and SURVEY 8(f) rows that round 1 left without oracle evidence:
+
+  configs[4]  2 M points at 3840x2160, forward + BACKWARD, against the reference build (oracle/_ref);
+  configs[0]  synth-THuman-256 (200 K voxelised points) at the reference's native 1024x1024 raster (512^2 x super-sample 2)
+              through the fused four-pass renderer; every pass against Oracle.forward (plain-C CPU oracle);
+  8f-1        colour-only re-render (gsr_forward_recolor) against the oracle (not against the product);
+  8f-2        a PLY written in open3d's layout, ingested with pcrender.ply, rendered by the HIP path, against the oracle;
+  8f-4        an OBJ mesh sampled with pcrender.mesh_sample (uniform and uniform_quantized), rendered, against the oracle;
+  gradients   per-element / per-Gaussian-row bars (util.check_grads) and a directional finite difference of the HIP
+              forward in position, scale and rotation.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import build_scene, check_grads, run_product
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+MAX_FLIP_FRACTION = 2e-3
+NTHREADS = os.cpu_count() or 1
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _ref():
+    from oracle.oracle import Reference
+    if not Reference.available("strict"):
+        pytest.skip("oracle/_ref not built")
+    return Reference("strict")
+
+
+def _image_close(got, want, tag):
+    """Rendered RGB within 1e-4 on every pixel that is not a threshold flip (glibc vs ocml expf can put an alpha or a T on
+    different sides of a cut); flips are counted and bounded."""
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    while err.ndim > 2:
+        err = err.max(axis=0) if err.shape[0] == 3 else err.max(axis=-1)
+    flips = err > RGB_TOL
+    assert flips.mean() <= MAX_FLIP_FRACTION, "%s: %d pixels beyond 1e-4 (%.2e of the image, max %.3g)" % (
+        tag, int(flips.sum()), flips.mean(), err.max())
+    return int(flips.sum())
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_config4_2m_points_4k_backward_vs_reference_build(gpu_device):
+    from pcrender import camera, synth
+    ref = _ref()
+    cloud = synth.make_cloud("synth-mesh-2M", seed=0)
+    g = synth.make_gaussians(cloud, profile="training", seed=1)
+    W, H = 3840, 2160
+    v = camera.circle_views(12, fov_deg=45.0, width_px=W, height_px=H)[5]
+    s = util.scene_from(g, v, W, H, bg=(1, 1, 1))
+    dL = util.seeded_dL(s)
+    r, gr = ref.forward_backward(s, dL)
+    p, gp = run_product(s, gpu_device, dL_dpix=dL, light=True)
+    assert p["R"] == r["R"] and p["R"] > 50_000_000
+    np.testing.assert_array_equal(p["radii"], r["radii"])
+    assert p["out_color"].tobytes() == r["out_color"].tobytes()
+    check_grads(gp, gr, "2M/4K vs reference build")
+
+
+# ------------------------------------------------------------------------------------------------ configs[0]
+def test_config0_thuman256_native_raster_four_passes_vs_oracle(oracle, gpu_device):
+    """The reference's real use (simple_benchmark.py pcrender, THuman-256 voxelised, camera 512x512 x super-sample 2):
+    xyz / rgb / hit map / normals from ONE geometry pass per view, each against an independent oracle forward."""
+    import torch.nn.functional as F
+    from oracle.oracle import Scene
+    from pcrender import camera, raster_passes as rp, synth
+    dev = gpu_device
+    cloud = synth.make_cloud("synth-THuman-256", seed=0)           # 200 000 points
+    g = synth.make_gaussians(cloud, profile="inference", seed=1)
+    sf = cloud["scale_factor"]
+    radius = float(np.sqrt(3) / sf * 6)
+    decoded_s = (g["scales"] / radius).astype(np.float32)
+    normals = g["means3D"] / np.linalg.norm(g["means3D"], axis=1, keepdims=True)
+    Hs = camera.circle_path(12, 0, 3, [90, 0])[[0, 1]]            # view 0 is axis aligned (depth ties), view 1 oblique
+    h = w = 512
+    ss = 2
+    bg = torch.ones(3)
+    fused = rp.render_passes(_t(g["means3D"], dev), _t(g["opacities"], dev), _t(decoded_s, dev), _t(g["rotations"], dev),
+                             _t(g["shs"], dev), Hs, h, w, 45.0, bg, sf, normals=_t(normals.astype(np.float32), dev),
+                             sh_degree=1, super_sample_rate=ss)
+    scales = (torch.from_numpy(decoded_s) * radius).numpy()       # the caller's fp32 multiply (simple_raw_render.py:248-249)
+    means_t = torch.from_numpy(g["means3D"])
+    colors_n = torch.from_numpy(normals.astype(np.float32))
+    total_flips = 0
+    for j in range(Hs.shape[0]):
+        a = camera.raster_settings_arrays(Hs[j], w, h, 45.0, ss)
+        assert a["image_height"] == 1024 and a["image_width"] == 1024
+        cam_orig = Hs[j, :3, 3]
+        sgn = (torch.sum((means_t - cam_orig) * colors_n, -1, keepdim=True) > 0).float() * 2 - 1
+        colors_n = colors_n * (-1) * sgn[0]                       # carried across views like the reference's loop (quirk Q11)
+        passes = dict(rgb=dict(shs=g["shs"], sh_degree=1), xyz_w=dict(colors_precomp=g["means3D"]),
+                      hitmap=dict(colors_precomp=np.ones_like(g["means3D"])), normal=dict(colors_precomp=colors_n.numpy()))
+        for name, kw in passes.items():
+            sc = Scene(W=1024, H=1024, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=np.ones(3, np.float32),
+                       means3D=g["means3D"], opacities=g["opacities"], viewmatrix=a["viewmatrix"].numpy(),
+                       projmatrix=a["projmatrix"].numpy(), campos=a["campos"].numpy(), scales=scales, rotations=g["rotations"], **kw)
+            o = oracle.forward(sc, nthreads=NTHREADS)
+            assert o["R"] > 1_000_000
+            want = F.interpolate(torch.from_numpy(o["out_color"])[None], size=(h, w), mode="bilinear", align_corners=False)[0]
+            got = fused[name][0, j].permute(2, 0, 1).cpu()
+            total_flips += _image_close(got.numpy(), want.numpy(), "view %d pass %s" % (j, name))
+    print("configs[0] four passes x 2 views: %d pixels beyond 1e-4 in total" % total_flips)
+
+
+# ------------------------------------------------------------------------------------------------ 8f-1 recolor
+@pytest.mark.parametrize("name", ["capsule_circle", "big_splats", "culled_mix"])
+def test_recolor_vs_oracle(name, oracle, gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    from oracle.oracle import Scene
+    dev = gpu_device
+    s = build_scene(name)
+    e = torch.empty(0)
+    args = (_t(s.bg, dev), _t(s.means3D, dev), e, _t(s.opacities, dev), _t(s.scales, dev), _t(s.rotations, dev), 1.0, e,
+            _t(s.viewmatrix.reshape(4, 4), dev), _t(s.projmatrix.reshape(4, 4), dev), s.tanfovx, s.tanfovy, s.H, s.W,
+            _t(s.shs, dev), s.sh_degree, _t(s.campos, dev), False, False)
+    R, rgb, radii, geom, binning, img = N.rasterize_gaussians(*args, need_backward=False)
+    rng = np.random.default_rng(5)
+    for colors in (s.means3D, np.ones_like(s.means3D), rng.uniform(-1, 1, s.means3D.shape).astype(np.float32)):
+        got = N.recolor(args[0], args[1], _t(colors, dev), e, 0, args[16], s.H, s.W, R, geom, binning, img).cpu().numpy()
+        s2 = Scene(W=s.W, H=s.H, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=s.bg, means3D=s.means3D, opacities=s.opacities,
+                   viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, campos=s.campos, colors_precomp=colors, scales=s.scales,
+                   rotations=s.rotations)
+        o = oracle.forward(s2)
+        assert o["R"] == R
+        _image_close(got, o["out_color"], name + " recolor")
+    again = N.recolor(args[0], args[1], e, args[14], s.sh_degree, args[16], s.H, s.W, R, geom, binning, img).cpu().numpy()
+    _image_close(again, oracle.forward(s)["out_color"], name + " recolor back to SH")
+
+
+# ------------------------------------------------------------------------------------------------ 8f-2 PLY ingest
+def _render_simple_vs_oracle(oracle, dev, prim, W, H, view_id, tag, backward=True):
+    """Simple_Render primitives (isotropic, opacity 1, SH DC) through the HIP path vs the oracle: integers exact, RGB to
+    1e-4, gradients to the per-element bar."""
+    from pcrender import camera
+    v = camera.circle_views(12, fov_deg=45.0, width_px=W, height_px=H)[view_id]
+    s = util.scene_from(prim, v, W, H, bg=(1, 1, 1))
+    dL = util.seeded_dL(s) if backward else None
+    if backward:
+        o, go = oracle.forward_backward(s, dL, nthreads=NTHREADS)
+    else:
+        o, go = oracle.forward(s, nthreads=NTHREADS), None
+    p, gp = run_product(s, dev, dL_dpix=dL)
+    assert p["R"] == o["R"] and p["R"] > 0
+    for k in ("radii", "tiles_touched", "vals", "keys", "ranges"):
+        np.testing.assert_array_equal(p[k], o[k], err_msg="%s %s" % (tag, k))
+    _image_close(p["out_color"], o["out_color"], tag)
+    if backward and not (p["n_contrib"] != o["n_contrib"]).any():
+        check_grads(gp, go, tag)
+    return p
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_ply_ingested_cloud_vs_oracle(binary, oracle, gpu_device, tmp_path):
+    """A voxelised cloud written the way the reference's data is stored (open3d layout, voxel coordinates, uchar colours;
+    simple_benchmark.py:171-184), read back with pcrender.ply, rescaled with pcgc_rescale and turned into the model-free
+    Simple_Render primitives (simple_raw_render.py:688-726)."""
+    from pcrender import ply, synth
+    cloud = synth.make_cloud("synth-THuman-256", seed=3, P=30000)
+    vox = np.round(cloud["means3D"].astype(np.float64) * 256.0 + 512.0)
+    path = str(tmp_path / "pcd_0.ply")
+    if binary:
+        rec = np.zeros(vox.shape[0], dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+        rec["x"], rec["y"], rec["z"] = vox[:, 0], vox[:, 1], vox[:, 2]
+        c8 = np.clip(np.round(cloud["rgb"].astype(np.float64) * 255.0), 0, 255).astype(np.uint8)
+        rec["red"], rec["green"], rec["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
+        with open(path, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty double x\nproperty double y\n"
+                     "property double z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % vox.shape[0]).encode())
+            f.write(rec.tobytes())
+    else:
+        ply.write_ply_ascii(path, vox, colors=cloud["rgb"])
+    d = ply.read_ply(path)
+    np.testing.assert_array_equal(d["points"], vox)
+    pts = ply.pcgc_rescale(d["points"], offset=512, factor=256)
+    prim = ply.simple_render_primitives(pts, d["colors"], sigma=2.0, scale_factor=256.0, voxelized=True)
+    p = _render_simple_vs_oracle(oracle, gpu_device, prim, 320, 256, 2, "ply(%s)" % ("binary" if binary else "ascii"))
+    assert p["visible"] == 30000
+
+
+# ------------------------------------------------------------------------------------------------ 8f-4 mesh sampling
+def _write_box_obj(path):
+    """A closed box with per-vertex colours, 12 triangles (OBJ with the 'v x y z r g b' colour extension)."""
+    v = np.array([[x, y, z] for x in (-0.35, 0.35) for y in (-0.8, 0.8) for z in (-0.2, 0.2)], np.float64)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    with open(path, "w") as f:
+        for p in v:
+            c = 0.5 + 0.5 * np.sin(3.0 * p + np.array([0.0, 2.0, 4.0]))
+            f.write("v %.6f %.6f %.6f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], c[0], c[1], c[2]))
+        for a, b, c, d in quads:
+            f.write("f %d %d %d\nf %d %d %d\n" % (a + 1, b + 1, c + 1, a + 1, c + 1, d + 1))
+
+
+@pytest.mark.parametrize("method", ["uniform", "uniform_quantized"])
+def test_mesh_sampled_cloud_vs_oracle(method, oracle, gpu_device, tmp_path):
+    """sample_point_cloud_from_mesh.py's pipeline: OBJ -> area-weighted samples (-> 448-per-unit voxel grid, one point per
+    voxel) -> Simple_Render primitives -> HIP render, against the oracle."""
+    from pcrender import mesh_sample as ms, ply
+    path = str(tmp_path / "box.obj")
+    _write_box_obj(path)
+    mesh = ms.read_obj(path)
+    pc = ms.sample_point_cloud(mesh, 40000, method=method, seed=4)
+    if method == "uniform_quantized":
+        assert np.array_equal(pc["xyz_w"], np.round(pc["xyz_w"]))             # voxel coordinates
+        assert np.unique(pc["xyz_w"], axis=0).shape[0] == pc["xyz_w"].shape[0]  # one point per voxel
+        means = ms.to_gaussian_means(pc["xyz_w"])
+        prim = ply.simple_render_primitives(means, pc["rgb"], sigma=2.0, scale_factor=448.0, voxelized=True)
+    else:
+        prim = ply.simple_render_primitives(pc["xyz_w"], pc["rgb"], sigma=0.004)
+    _render_simple_vs_oracle(oracle, gpu_device, prim, 288, 272, 4, "mesh(%s)" % method)
+
+
+# ------------------------------------------------------------------------------------------------ finite differences
+def _fd_single_gaussians(s, dev, g, dL, field, grad_key, rel_eps, K, rng, tag):
+    """Central differences of loss = sum(image * dL) of the HIP forward, perturbing ONE Gaussian at a time along a random
+    direction in ONE input tensor, against the analytic directional derivative of that Gaussian.  Returns (slope of the
+    least-squares line FD = slope * analytic, Pearson correlation) over K Gaussians."""
+    from oracle.oracle import Scene
+    base = getattr(s, field)
+    gk = g[grad_key].astype(np.float64).reshape(base.shape)
+    strength = np.linalg.norm(gk, axis=1)
+    cand = np.nonzero(strength > np.quantile(strength[strength > 0], 0.5))[0]   # Gaussians that matter to this loss
+    pick = rng.choice(cand, size=min(K, cand.size), replace=False)
+    fd, an = [], []
+    for k in pick:
+        d = rng.standard_normal(base.shape[1])
+        d /= np.linalg.norm(d)
+        step = rel_eps * (np.abs(s.scales[k]).mean() if field != "rotations" else 1.0)
+        vals = []
+        thetas = []
+        for sign in (+1, -1):
+            arr = base.copy()
+            arr[k] = (base[k].astype(np.float64) + sign * step * d).astype(np.float32)
+            kw = dict(means3D=s.means3D, opacities=s.opacities, scales=s.scales, rotations=s.rotations)
+            kw[field] = arr
+            s2 = Scene(W=s.W, H=s.H, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=s.bg, viewmatrix=s.viewmatrix,
+                       projmatrix=s.projmatrix, campos=s.campos, shs=s.shs, sh_degree=s.sh_degree, **kw)
+            img = run_product(s2, dev, light=True)[0]["out_color"].astype(np.float64)
+            vals.append(float((img * dL).sum()))
+            thetas.append(arr[k].astype(np.float64))
+        fd.append(vals[0] - vals[1])
+        an.append(float(gk[k] @ (thetas[0] - thetas[1])))       # the float32 values actually rendered define the step
+    fd, an = np.asarray(fd), np.asarray(an)
+    slope = float((fd * an).sum() / (an * an).sum())
+    corr = float(np.corrcoef(fd, an)[0, 1])
+    print("%s %s: %d Gaussians, FD = %.4f x analytic, correlation %.5f" % (tag, field, fd.size, slope, corr))
+    return slope, corr
+
+
+@pytest.mark.parametrize("which", ["capsule_circle", "thuman800k_1080p"])
+def test_gradient_matches_finite_difference_in_position_scale_rotation(which, gpu_device):
+    """The analytic gradients of the geometric inputs against a numerical derivative of the HIP forward itself (the parity
+    tests only compare them with other implementations).  One Gaussian is moved at a time, so nothing cancels; the
+    rendered function is only piecewise smooth (the alpha >= 1/255 cut, the 0.99 clamp, the T < 1e-4 stop and the 3-sigma
+    tile rectangle switch contributions of ~0.4 % of full scale on and off, and no implementation's gradient -- the
+    reference's included -- contains those jump terms), which adds zero-mean scatter to single differences; the regression
+    over many Gaussians must still have slope 1 and a correlation close to 1."""
+    from pcrender import camera, synth
+    if which == "capsule_circle":
+        s, K = build_scene(which), 192
+    else:
+        cloud = synth.make_cloud("synth-THuman-800K", seed=0)
+        gg = synth.make_gaussians(cloud, profile="training", seed=1)
+        v = camera.circle_views(12, fov_deg=45.0, width_px=1920, height_px=1080)[3]
+        s, K = util.scene_from(gg, v, 1920, 1080, bg=(1, 1, 1)), 48
+    dL = util.seeded_dL(s)
+    _, g = run_product(s, gpu_device, dL_dpix=dL, light=True)
+    rng = np.random.default_rng(77)
+    for field, key, rel_eps in (("means3D", "dL_dmean3D", 0.05), ("scales", "dL_dscale", 0.05), ("rotations", "dL_drot", 0.02)):
+        slope, corr = _fd_single_gaussians(s, gpu_device, g, dL, field, key, rel_eps, K, rng, which)
+        assert abs(slope - 1.0) <= 0.03 and corr >= 0.98, (field, slope, corr)

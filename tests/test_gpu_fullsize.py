@@ -65,10 +65,7 @@ def test_fullsize_backward_vs_reference_build(gpu_device):
     dL = util.seeded_dL(s)
     _, gr = ref.forward_backward(s, dL)
     _, gp = run_product(s, gpu_device, dL_dpix=dL)
-    for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"):
-        a, b = gp[k].astype(np.float64).ravel(), gr[k].astype(np.float64).ravel()
-        assert np.isfinite(a).all()
-        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), k
+    util.check_grads(gp, gr, "800K/1080p vs reference build")
 
 
 def test_fullsize_structural_properties(gpu_device):
@@ -176,6 +173,4 @@ def test_more_than_65536_tiles_uses_32_bit_tile_keys(gpu_device):
     dL = util.seeded_dL(s)
     _, gr = ref.forward_backward(s, dL)
     _, gp = run_product(s, gpu_device, dL_dpix=dL)
-    for k in ("dL_dmean2D", "dL_dopacity", "dL_dmean3D", "dL_dsh"):
-        a, b = gp[k].astype(np.float64), gr[k].astype(np.float64)
-        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-30, k
+    util.check_grads(gp, gr, ">65536 tiles vs reference build")

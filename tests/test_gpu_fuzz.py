@@ -77,7 +77,8 @@ def test_random_case_matches_reference_build(i, gpu_device):
         assert np.isfinite(a).all(), "case %d %s" % (i, k)
         scale = np.abs(b).max()
         d_ref = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
-        if d_ref <= 2e-4 * scale + 1e-30:
+        bad_el, bad_row, _ = util.grad_violations(a, b)
+        if bad_el == 0 and bad_row == 0:
             continue
         # Both sides sum thousands of fp32 terms in different (for the reference: unspecified, atomic) orders, and the
         # per-Gaussian chain conic -> cov3D -> scale / rotation can amplify that rounding noise by 10^3 on an
@@ -87,7 +88,12 @@ def test_random_case_matches_reference_build(i, gpu_device):
         if oracle_grads is None:
             from oracle.oracle import Oracle
             oracle_grads = Oracle().forward_backward(s, dL)[1]
-        o = oracle_grads[k].astype(np.float64)
-        d_lib, d_build = np.abs(a - o).max(), np.abs(b - o).max()
-        assert d_lib <= max(4 * d_build, 2e-4 * scale), "case %d %s: lib-oracle %.3g, ref-oracle %.3g, lib-ref %.3g, max|g| %.3g" % (
-            i, k, d_lib, d_build, d_ref, scale)
+        o = oracle_grads[k].astype(np.float64).reshape(a.shape[0], -1)
+        a2, b2 = a.astype(np.float64).reshape(a.shape[0], -1), b.astype(np.float64).reshape(a.shape[0], -1)
+        rn = np.linalg.norm(o, axis=1)
+        r_lib, r_build = np.linalg.norm(a2 - o, axis=1), np.linalg.norm(b2 - o, axis=1)
+        # per Gaussian row: inside the usual bar against the double-precision oracle, or no further from it than 4x the
+        # reference build's own distance for that row
+        ok = r_lib <= np.maximum(util.ROW_REL * rn + util.ROW_ABS * rn.max(), 4 * r_build) + 1e-30
+        assert ok.all(), "case %d %s: %d rows; worst lib-oracle %.3g (ref-oracle %.3g there), lib-ref max %.3g, max|g| %.3g" % (
+            i, k, int((~ok).sum()), r_lib[~ok].max(), r_build[~ok][np.argmax(r_lib[~ok])], d_ref, scale)

@@ -8,7 +8,9 @@ Bars (BASELINE.json north_star / SURVEY.md 8c):
   * per-Gaussian forward floats (means2D, depth, conic, rgb) bit-exact vs both (only IEEE +,-,*,/,sqrt involved);
   * rendered RGB: bit-exact vs the reference build (same exp, same op order); vs the CPU oracle (glibc expf vs
     ocml expf can differ in the last bit) max-abs <= 1e-4 on every pixel that is not a threshold flip, flips counted;
-  * gradients: max|d| <= 2e-4 * max|g| per tensor (float accumulation order differs by construction).
+  * gradients: per element |a - b| <= 1e-4 * max|g| + 1e-3 * |b| and per Gaussian row
+    ||a_i - b_i|| <= 2e-3 * ||b_i|| + 1e-4 * max_j ||b_j|| (util.check_grads; float accumulation order differs by
+    construction, so not bit-exact).
 """
 import numpy as np
 import pytest
@@ -19,7 +21,6 @@ from util import SCENES, build_scene, run_product, seeded_dL
 pytestmark = pytest.mark.gpu
 
 RGB_TOL = 1e-4          # north_star: "within 1e-4 max abs (fp32)"
-GRAD_REL_TOL = 2e-4     # of max|g| per gradient tensor
 MAX_FLIP_FRACTION = 2e-3
 
 
@@ -85,16 +86,9 @@ def test_forward_vs_reference_build_bit_exact(name, gpu_device):
     assert p["out_color"].tobytes() == r["out_color"].tobytes(), "out_color differs: max abs %g" % np.abs(p["out_color"] - r["out_color"]).max()
 
 
-def _check_grads(gp, go, tag, tol=GRAD_REL_TOL):
-    for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot"):
-        a, b = gp[k].reshape(-1).astype(np.float64), go[k].reshape(-1).astype(np.float64)
-        assert a.shape == b.shape, (tag, k, gp[k].shape, go[k].shape)
-        if a.size == 0:
-            continue
-        assert np.isfinite(a).all(), "%s %s: non-finite gradient" % (tag, k)
-        scale = np.abs(b).max()
-        d = np.abs(a - b).max()
-        assert d <= tol * scale + 1e-30, "%s %s: max|d|=%g vs %g*max|g|=%g" % (tag, k, d, tol, tol * scale)
+def _check_grads(gp, go, tag):
+    # per element |a-b| <= 1e-4 max|g| + 1e-3 |b|, and per Gaussian row ||a_i-b_i|| <= 2e-3 ||b_i|| + 1e-4 max row norm
+    util.check_grads(gp, go, tag)
 
 
 BWD_SCENES = [n for n in SCENES if n not in ("all_culled",)]

@@ -162,9 +162,10 @@ def seeded_dL(scene, seed=123):
 
 
 # ------------------------------------------------------------------------------------------ product runner
-def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None):
+def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None, light=False):
     """Run the HIP library through the package's native binding; returns (forward dict, grads dict or None) with the
-    same keys/shapes as oracle.Oracle.forward."""
+    same keys/shapes as oracle.Oracle.forward.  light=True skips the copies of the private arena arrays (only R, the
+    image and radii are returned): for full-size scenes where they are not compared."""
     import torch
     from diff_gaussian_rasterization import _native as N
 
@@ -179,7 +180,7 @@ def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None):
     R, color, radii, geom, binning, img = N.rasterize_gaussians(*args, need_backward=nb)
     P, W, H = scene.P, scene.W, scene.H
     out = dict(P=P, W=W, H=H, R=R, out_color=color.cpu().numpy(), radii=radii.cpu().numpy())
-    if P:
+    if P and not light:
         def q(name):
             return N.query(name, P, W, H, R, geom, binning, img).cpu().numpy()
         out.update(
@@ -208,3 +209,45 @@ def ulp_diff(a, b):
     a = np.where(a < 0, np.int64(-2**31) - a, a)
     b = np.where(b < 0, np.int64(-2**31) - b, b)
     return np.abs(a - b)
+
+
+# ------------------------------------------------------------------------------------------ gradient bars
+GRAD_NAMES = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+GRAD_ABS = 1e-4     # of max|g| of the tensor
+GRAD_REL = 1e-3     # of the element's own reference value
+ROW_REL = 2e-3      # per-Gaussian row norm, relative
+ROW_ABS = 1e-4      # ... plus this fraction of the largest row norm of the tensor
+
+
+def grad_violations(a, b):
+    """Per-element and per-Gaussian-row comparison of one gradient tensor (a = library, b = reference), in float64:
+         element:  |a - b| <= GRAD_ABS * max|b| + GRAD_REL * |b|
+         row:      ||a_i - b_i|| <= ROW_REL * ||b_i|| + ROW_ABS * max_j ||b_j||        (row = one Gaussian)
+    Returns (number of violating elements, number of violating rows, worst element excess ratio)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64).reshape(a.shape)
+    if a.size == 0:
+        return 0, 0, 0.0
+    scale = np.abs(b).max()
+    bound = GRAD_ABS * scale + GRAD_REL * np.abs(b) + 1e-30
+    d = np.abs(a - b)
+    bad_el = int((d > bound).sum())
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    rn = np.linalg.norm(b2, axis=1)
+    rd = np.linalg.norm(a2 - b2, axis=1)
+    bad_row = int((rd > ROW_REL * rn + ROW_ABS * rn.max() + 1e-30).sum())
+    return bad_el, bad_row, float((d / bound).max())
+
+
+def check_grads(gp, go, tag, names=GRAD_NAMES):
+    """Assert every gradient tensor of the library (gp) against a reference (go): finite, same shape, per-element and
+    per-row bars of grad_violations."""
+    for k in names:
+        a, b = gp[k], go[k]
+        if a.size == 0 and np.asarray(b).size == 0:
+            continue
+        assert a.size == np.asarray(b).size, (tag, k, a.shape, np.asarray(b).shape)
+        assert np.isfinite(a).all(), "%s %s: non-finite gradient" % (tag, k)
+        bad_el, bad_row, worst = grad_violations(a, b)
+        assert bad_el == 0 and bad_row == 0, "%s %s: %d elements / %d rows outside the bar (worst element at %.2fx its bound)" % (
+            tag, k, bad_el, bad_row, worst)
