@@ -52,7 +52,7 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv)
     return r;
 }
 
-constexpr int SH_MAX_ROWS = 16;
+template <int DEG> constexpr int sh_words() { return 3 * (DEG + 1) * (DEG + 1); }
 
 struct PreBwdArgs {
     int P, D, M, V;
@@ -69,8 +69,9 @@ struct PreBwdArgs {
 
 // SH backward (reference CR/backward.cu:20-139): adds this view's dL_dsh rows into acc, returns the mean gradient through the
 // normalised view direction.
-__device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t cmask, V3 dL_dRGB,
-                                          float (&acc)[SH_MAX_ROWS * 3])
+template <int deg>
+__device__ __forceinline__ V3 sh_backward(V3 pos, V3 campos, const float* __restrict__ sh, uint32_t cmask, V3 dL_dRGB,
+                                          float (&acc)[sh_words<deg>()])
 {
     const V3 dir_orig = pos - campos;
     const float len = sqrtf(dot3(dir_orig, dir_orig));
@@ -83,14 +84,14 @@ __device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const floa
 #define SHV(k) v3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
 #define PUT(k, s) do { const V3 t_ = (s) * dL_dRGB; acc[3 * (k)] += t_.x; acc[3 * (k) + 1] += t_.y; acc[3 * (k) + 2] += t_.z; } while (0)
     PUT(0, kSH_C0);
-    if (deg > 0) {
+    if constexpr (deg > 0) {
         PUT(1, -kSH_C1 * y);
         PUT(2, kSH_C1 * z);
         PUT(3, -kSH_C1 * x);
         dRGBdx = -kSH_C1 * SHV(3);
         dRGBdy = -kSH_C1 * SHV(1);
         dRGBdz = kSH_C1 * SHV(2);
-        if (deg > 1) {
+        if constexpr (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z;
             const float xy = x * y, yz = y * z, xz = x * z;
             PUT(4, kSH_C2[0] * xy);
@@ -103,7 +104,7 @@ __device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const floa
             dRGBdy = dRGBdy + ((((kSH_C2[0] * x) * SHV(4) + (kSH_C2[1] * z) * SHV(5)) + (kSH_C2[2] * 2.f * -y) * SHV(6)) +
                                (kSH_C2[4] * 2.f * -y) * SHV(8));
             dRGBdz = dRGBdz + (((kSH_C2[1] * y) * SHV(5) + (kSH_C2[2] * 2.f * 2.f * z) * SHV(6)) + (kSH_C2[3] * x) * SHV(7));
-            if (deg > 2) {
+            if constexpr (deg > 2) {
                 PUT(9, kSH_C3[0] * y * (3.f * xx - yy));
                 PUT(10, kSH_C3[1] * xy * z);
                 PUT(11, kSH_C3[2] * y * (4.f * zz - xx - yy));
@@ -144,6 +145,8 @@ __device__ __forceinline__ V3 sh_backward(int deg, V3 pos, V3 campos, const floa
     return dnormvdv(dir_orig, dL_ddir);
 }
 
+// DEG = active SH degree (a template parameter so that the per-view SH sums take 3 (DEG+1)^2 registers, not 48)
+template <int DEG>
 __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
     V3 gcol = v3(0, 0, 0), gmean = v3(0, 0, 0);
     float gS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gsh[SH_MAX_ROWS * 3];
+    constexpr int NSH = sh_words<DEG>();
+    float gsh[NSH];
 #pragma unroll
-    for (int i = 0; i < SH_MAX_ROWS * 3; i++) gsh[i] = 0.f;
+    for (int i = 0; i < NSH; i++) gsh[i] = 0.f;
 
     const V3 mean = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     // 3D covariance as the forward saw it (recomputed with the forward's code, not stored)
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
         if (a.shs) {
             const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
             const uint8_t cm = at_view(a.clamped, a.g_stride, (uint32_t)vw)[idx];
-            dmean = dmean + sh_backward(a.D, mean, cam, a.shs + (size_t)idx * a.M * 3, cm, v3(rec1.y, rec1.z, rec1.w), gsh);
+            dmean = dmean + sh_backward<DEG>(mean, cam, a.shs + (size_t)idx * a.M * 3, cm, v3(rec1.y, rec1.z, rec1.w), gsh);
         }
         gmean = gmean + dmean;
     }
@@ -259,11 +263,9 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gS[i];
     if (a.shs) {
         float* out = a.dL_dsh + (size_t)idx * a.M * 3;
-        const int used = 3 * (a.D + 1) * (a.D + 1);
 #pragma unroll
-        for (int i = 0; i < SH_MAX_ROWS * 3; i++)
-            if (i < used) out[i] = gsh[i];
-        for (int i = used; i < 3 * a.M; i++) out[i] = 0.f;
+        for (int i = 0; i < NSH; i++) out[i] = gsh[i];
+        for (int i = NSH; i < 3 * a.M; i++) out[i] = 0.f;
     }
 
     // ---- 3D covariance -> scale, rotation (the sum over views entered gS linearly, so this runs once)
@@ -312,7 +314,13 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch
     a.grad_rec = B.g.grad_rec; a.g_stride = B.g_stride;
     a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
-    hipLaunchKernelGGL(k_preprocess_backward, dim3((p.P + 255) / 256), dim3(256), 0, L.stream, a);
+    const dim3 grid((p.P + 255) / 256), block(256);
+    switch (p.shs ? p.D : 0) {
+    case 0: hipLaunchKernelGGL(k_preprocess_backward<0>, grid, block, 0, L.stream, a); break;
+    case 1: hipLaunchKernelGGL(k_preprocess_backward<1>, grid, block, 0, L.stream, a); break;
+    case 2: hipLaunchKernelGGL(k_preprocess_backward<2>, grid, block, 0, L.stream, a); break;
+    default: hipLaunchKernelGGL(k_preprocess_backward<3>, grid, block, 0, L.stream, a); break;
+    }
     return check_launch(L, "preprocess_backward");
 }
 
