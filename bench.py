@@ -7,10 +7,13 @@ Workload (BASELINE.json metric, configs[2]): synth-THuman-800K -- 
 `circle` cameras, forward + backward through the public GaussianRasterizer API, loss = sum(img * G).
 A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered on
 rank 0 with RCCL (weak scaling).  All inputs are resident in HBM before the timed region.
-Views are independent, so each rank keeps --streams (default 4) frames in flight: that many host threads, each
-rendering whole frames (forward + backward) on its own HIP stream; the tail of one frame's render kernels overlaps
-the bandwidth-bound stages of the next.  The single-stream rate and the per-stage timings are measured in a second,
-single-stream pass right after the timed region and reported next to the headline value.
+Frames are submitted --views-per-call (default 12, one turn of the circle) at a time through rasterize_views -- the C ABI's
+gsr_forward_batch / gsr_backward_batch: every kernel covers all views of the submission, nothing on the host waits for
+the device inside a frame, gradients of the shared cloud are summed over the views on the device -- with --streams (default
+2) submissions in flight on their own HIP streams.  K steps that are not a multiple of the batch end with a smaller batch.
+The per-stage timings and the single-stream rate come from a single-stream pass right after the timed region; the same
+frames through the reference's per-view call (one GaussianRasterizer call per view) are timed next to it
+(`per_view_api_frames_per_s`).
 
 `--gpus N` with N > 1 and no torch.distributed.run environment re-launches itself under torch.distributed.run with N ranks
 (one per GPU, RCCL); it refuses loudly when the box has fewer than N GPUs.  The timed region is `--repeats` (default 5)
@@ -77,13 +80,14 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "1")),
+    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "12")),
                     help="frames submitted per rasterizer call: 1 = the reference's per-view GaussianRasterizer call; V > 1 = "
                          "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission")
+    ap.add_argument("--no-per-view", action="store_true", help="skip the per-view-API comparison pass")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the all-core CPU baseline (after 1 warm-up)")
     ap.add_argument("--no-cpu-1core", action="store_true", help="skip the 1-core CPU figure (about a minute of CPU time)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "4")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "2")),
                     help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 lets several ranks share one GPU to exercise the multi-rank control flow "
@@ -150,7 +154,7 @@ def main():
                     opacities=leaf(g["opacities"]), scales=leaf(g["scales"]), rotations=leaf(g["rotations"]))
 
     # one set of leaf tensors per host thread (their .grad is written by that thread's backward only)
-    leafsets = [make_leaves() for _ in range(max(1, args.streams))]
+    leafsets = [make_leaves() for _ in range(max(4, args.streams))]
     means3D, shs, opac = leafsets[0]["means3D"], leafsets[0]["shs"], leafsets[0]["opacities"]
     scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
@@ -177,7 +181,7 @@ def main():
 
     def render_many(i, n, tslot=0):
         """Global steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
-        if VPC == 1:
+        if n == 1:
             return render(i, tslot)[None]
         L = leafsets[tslot]
         sts = [settings[((i + k) * world + rank) % n_views] for k in range(n)]
@@ -207,14 +211,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(first, count, streams=None):
+    def run_steps(first, count, streams=None, vpc=None):
         """`count` steps from global step `first`, submitted --views-per-call at a time, --streams submissions in flight
         (pcrender.multiview.run_frames_pipelined); the frame gather is issued by this thread only, in step order, so every
         rank enqueues collectives identically."""
         ch = []
         i = first
         while i < first + count:
-            n = min(VPC, first + count - i)
+            n = min(VPC if vpc is None else vpc, first + count - i)
             ch.append((i, n))
             i += n
         multiview.run_frames_pipelined(lambda ci, slot: render_many(ch[ci][0], ch[ci][1], slot), 0, len(ch),
@@ -256,6 +260,21 @@ def main():
         _native.set_profiling(False)
         single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1}
         kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % n1
+    per_view = None
+    if rank == 0 and VPC > 1 and not args.no_per_view:
+        # the same frames through the reference's per-view call (GaussianRasterizer, one view per submission), for comparison
+        _gather_on, do_gather = do_gather, False
+        per_view = {}
+        for name, st in (("one_stream", 1), ("four_streams", 4)):
+            if st > len(leafsets):
+                continue
+            run_steps(warm, 12, streams=st, vpc=1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(warm, 48, streams=st, vpc=1)
+            torch.cuda.synchronize()
+            per_view[name] = round(48 / (time.perf_counter() - t1), 1)
+        do_gather = _gather_on
     if use_dist:
         t = torch.tensor(block_dt, device="cpu" if host_collectives else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -363,6 +382,7 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()}, "kernel_timing": kernel_timing,
             "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},
             "streams_per_rank": args.streams, "single_stream": single,
+            "per_view_api_frames_per_s": per_view,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
                           "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
         }

@@ -551,6 +551,10 @@ int gsr_get_profile(const char** names, float* ms, int cap)
     return n;
 }
 
+#ifdef GSR_STATS
+__attribute__((visibility("default"))) int gsr_debug_bwd_stats(unsigned long long* out8, int reset) { return gsr::debug_bwd_stats(out8, reset); }
+#endif
+
 const char* gsr_last_error(void) { return gsr::g_err; }
 const char* gsr_version(void) { return "gsr-hip 0.2 (gfx950)"; }
 

@@ -262,6 +262,9 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
                           bool with_ckpt);
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix);
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
+#ifdef GSR_STATS
+int debug_bwd_stats(unsigned long long* out8, int reset);   // instrumentation build only
+#endif
 // preprocess_bwd.hip
 // reads grad_rec of every view; writes the user-facing gradients summed over the views of the batch
 int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch& B, const int* radii, float* dL_dmean2D,

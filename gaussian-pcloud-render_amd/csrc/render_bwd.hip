@@ -196,6 +196,15 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
     return 0;
 }
 
+#ifdef GSR_STATS
+// instrumentation build only (GSR_EXTRA_FLAGS=-DGSR_STATS): 0 rounds, 1 staged entries, 2 groups, 3 groups with a hit,
+// 4 entries with a hit, 5 (pixel, entry) hits
+__device__ unsigned long long g_bwd_stats[8];
+#define BWD_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bwd_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define BWD_STAT(i, v) do { } while (0)
+#endif
+
 struct RenderBwdArgs {
     const uint2* ranges;
     const uint32_t* items;       // work items: tile | chunk << BWD_TILE_BITS, heaviest first (binning.hip k_bwd_items)
@@ -365,8 +374,11 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 p[24] = c1.z; p[28] = c1.w; p[32] = c2b; p[36] = __builtin_bit_cast(float, id_cur);
             }
         }
+        BWD_STAT(0, 1);
+        BWD_STAT(1, __popcll(mask));
         int quad = 0;
         while (mask != 0) {
+            BWD_STAT(2, 1);
             float ex[BGRP], ey[BGRP], eA[BGRP], eB[BGRP], eC[BGRP], eo[BGRP], er[BGRP], eg[BGRP], eb[BGRP];
             uint32_t ef[BGRP];
             {
@@ -408,6 +420,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 any_lane_hit = any_lane_hit || hits[k] || hits[k + 1];
             }
             if (!__any(any_lane_hit)) continue;
+#ifdef GSR_STATS
+            BWD_STAT(3, 1);
+            for (int k = 0; k < BGRP; k++) {
+                const uint64_t hm = __ballot(hits[k]);
+                BWD_STAT(4, hm != 0 ? 1 : 0);
+                BWD_STAT(5, __popcll(hm));
+            }
+#endif
 
             // Phase 1 (branch-free): advance the per-pixel recurrences through the four entries.
             // The reference tracks accum_rec[ch], the colour accumulated behind the current entry, only to form
@@ -481,6 +501,18 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     }
   }
 }
+
+#ifdef GSR_STATS
+int debug_bwd_stats(unsigned long long* out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix)
 {
