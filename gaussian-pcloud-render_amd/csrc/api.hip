@@ -8,7 +8,7 @@
 //             depth sort of the P Gaussians                       4 passes x 3 launches, u32 key / u32 id
 //             pair emission in depth order with its own prefix sum  1 launch     -> num_rendered, ON THE DEVICE
 //             tile sort                                           ceil(bit/8) passes x 3 launches, u16|u32 tile / u32 id
-//             tile ranges, tile order by list length              2 launches
+//             tile ranges (search), tile order by list length     2 launches
 //             render                                              1 launch
 //   backward  work items, render backward, per-Gaussian backward  3 launches
 //
@@ -499,7 +499,7 @@ int gsr_selftest(gsr_stream_t stream)
     }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
     uint32_t *k0, *k1, *v0, *v1, *hist, *tot;
-    const size_t nb = (size_t)div_up(n, RS_TILE);
+    const size_t nb = (size_t)sort_hist_stride(n);
     if (hipMalloc(&k0, n * 4) != hipSuccess || hipMalloc(&k1, n * 4) != hipSuccess || hipMalloc(&v0, n * 4) != hipSuccess ||
         hipMalloc(&v1, n * 4) != hipSuccess || hipMalloc(&hist, RADIX * nb * 4) != hipSuccess || hipMalloc(&tot, RADIX * 4) != hipSuccess)
         return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");

@@ -12,7 +12,8 @@
 //     wave's whole contiguous output range 64 slots at a time (coalesced 4-B stores) instead of one
 //     thread writing a 10..40-slot run on its own;
 //   - pairs beyond the binning arena's capacity are counted but not written (the host retries with a larger arena).
-// Tile ranges follow reference CR/rasterizer_impl.cu:116-138 (identifyTileRanges) + the memset at :310.
+// Tile ranges (reference CR/rasterizer_impl.cu:116-138 identifyTileRanges + the memset at :310): one thread per tile finds
+// its list in the sorted keys by binary search -- T searches instead of a pass over all R keys.
 #include "common.hpp"
 
 namespace gsr {
@@ -160,50 +161,71 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     return check_launch(L, "duplicate");
 }
 
-constexpr int RANGES_PER_THREAD = 4;
+// ---- tile ranges by search -------------------------------------------------------------------------------
+// ranges[t] = [lower_bound(keys, t), lower_bound(keys, t + 1)), or (0, 0) for a tile without pairs (what the reference's
+// memset leaves).  Two levels: every RANGE_SAMPLE-th key is staged in LDS and searched there, then one block of
+// RANGE_SAMPLE keys is searched in global memory (12 dependent loads instead of 24).  Every tile is written, so the array
+// needs no clearing.
+constexpr int RANGE_SAMPLE = 4096;
+constexpr int RANGE_MAX_SAMPLES = 8192;
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t lower_bound_keys(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ samples,
+                                                     uint32_t ns, uint32_t t)
+{
+    uint32_t lo = 0, hi = n;   // answer in [lo, hi]
+    if (ns != 0) {
+        // largest sample j with keys[j * RANGE_SAMPLE] < t  ->  the answer lies in (j * S, (j + 1) * S]
+        uint32_t a = 0, b = ns;   // first sample >= t is in [a, b]
+        while (a < b) {
+            const uint32_t m = (a + b) >> 1;
+            if (samples[m] < t) a = m + 1; else b = m;
+        }
+        if (a == 0) return 0;     // even keys[0] >= t
+        lo = (a - 1) * RANGE_SAMPLE + 1;
+        hi = a < ns ? a * RANGE_SAMPLE : n;
+    }
+    while (lo < hi) {
+        const uint32_t m = (lo + hi) >> 1;
+        if ((uint32_t)keys[m] < t) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
 
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict__ counters, size_t g_stride, int64_t cap,
                                                      const KeyT* __restrict__ keys, size_t b_stride, uint2* __restrict__ ranges,
-                                                     size_t iv_stride)
+                                                     size_t iv_stride, int T)
 {
+    __shared__ uint32_t samples[RANGE_MAX_SAMPLES];
     const uint32_t view = blockIdx.y;
     const uint64_t n64 = at_view(counters, g_stride, view)[CNT_NUM_RENDERED];
-    const int64_t R = n64 < (uint64_t)cap ? (int64_t)n64 : cap;
-    const int64_t base = (int64_t)blockIdx.x * (256 * RANGES_PER_THREAD);
-    if (base >= R) return;
+    const uint32_t n = (uint32_t)(n64 < (uint64_t)cap ? n64 : (uint64_t)cap);
     keys = at_view(keys, b_stride, view);
     ranges = at_view(ranges, iv_stride, view);
-#pragma unroll
-    for (int k = 0; k < RANGES_PER_THREAD; k++) {
-        const int64_t idx = base + k * 256 + threadIdx.x;
-        if (idx >= R) break;
-        const uint32_t cur = keys[idx];
-        if (idx == 0)
-            ranges[cur].x = 0;
-        else {
-            const uint32_t prev = keys[idx - 1];
-            if (cur != prev) {
-                ranges[prev].y = (uint32_t)idx;
-                ranges[cur].x = (uint32_t)idx;
-            }
-        }
-        if (idx == R - 1) ranges[cur].y = (uint32_t)R;
+    uint32_t ns = (n + RANGE_SAMPLE - 1) / RANGE_SAMPLE;
+    if (ns > RANGE_MAX_SAMPLES) ns = 0;   // enormous lists: plain binary search
+    for (uint32_t j = threadIdx.x; j < ns; j += 256) samples[j] = (uint32_t)keys[(size_t)j * RANGE_SAMPLE];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    uint2 r = make_uint2(0u, 0u);
+    if (n != 0) {
+        const uint32_t first = lower_bound_keys(keys, n, samples, ns, (uint32_t)t);
+        if (first < n && (uint32_t)keys[first] == (uint32_t)t) r = make_uint2(first, lower_bound_keys(keys, n, samples, ns, (uint32_t)t + 1u));
     }
+    ranges[t] = r;
 }
 
-// ranges[] was cleared at the start of the frame (k_preprocess, or the host on a retry)
 int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16)
 {
-    (void)T;
-    if (B.b.cap <= 0) return GSR_OK;
-    const dim3 grid((unsigned)div_up(B.b.cap, 256 * RANGES_PER_THREAD), B.V);
+    const dim3 grid((unsigned)div_up(T, 256), B.V);
     if (key16)
         hipLaunchKernelGGL(k_tile_ranges<uint16_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap,
-                           (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride);
+                           (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride, T);
     else
         hipLaunchKernelGGL(k_tile_ranges<uint32_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap, sorted_keys,
-                           B.b_stride, B.iv.ranges, B.iv_stride);
+                           B.b_stride, B.iv.ranges, B.iv_stride, T);
     return check_launch(L, "tile_ranges");
 }
 
@@ -222,7 +244,7 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
     return (ORD_BUCKETS - 2) - (rank < ORD_BUCKETS - 2 ? rank : ORD_BUCKETS - 2);
 }
 
-// One 1024-thread workgroup: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
+// One 1024-thread workgroup per view: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
 // wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
 // one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
 __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,

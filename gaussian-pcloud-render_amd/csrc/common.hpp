@@ -33,6 +33,9 @@ constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // keys per workgroup per pass
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
+// the count matrix of a sort is [digit][block] with rows padded to whole 64-B lines (sort.hip HIST_GROUP = 16 blocks)
+inline int sort_hist_stride(int64_t n) { return (int)(((n + RS_TILE - 1) / RS_TILE + 15) / 16 * 16); }
+
 constexpr int DUP_THREADS = 256;  // Gaussians per pair-emission workgroup (binning.hip)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -102,9 +105,9 @@ struct BinView {
 };
 
 struct ImageView {
-    uint2* ranges;        // [T]          } cleared by k_preprocess at the start of every frame
-    uint32_t* tile_need;  // [T] entries walked by the forward render }
-    uint32_t* bwd_count;  // [4] number of backward items             }
+    uint32_t* tile_need;  // [T] entries walked by the forward render  } cleared by k_preprocess at the start of
+    uint32_t* bwd_count;  // [4] number of backward items              } every frame
+    uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
     uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
@@ -128,7 +131,7 @@ inline GeomView geom_view(void* base, int P)
     GeomView g;
     char* cur = reinterpret_cast<char*>(base);
     const size_t p = (size_t)(P > 0 ? P : 1);
-    const size_t nblk = (size_t)div_up((int64_t)p, RS_TILE);
+    const size_t nblk = (size_t)sort_hist_stride((int64_t)p);
     carve(cur, g.splat, p);
     carve(cur, g.tiles_touched, p);
     carve(cur, g.rect, p);
@@ -153,7 +156,7 @@ inline BinView bin_view(void* base, int64_t cap)
     BinView b;
     char* cur = reinterpret_cast<char*>(base);
     const size_t r = (size_t)(cap > 0 ? cap : 1);
-    const size_t nblk = (size_t)div_up((int64_t)r, RS_TILE);
+    const size_t nblk = (size_t)sort_hist_stride((int64_t)r);
     carve(cur, b.key[0], r);
     carve(cur, b.key[1], r);
     carve(cur, b.val[0], r);
@@ -185,10 +188,10 @@ inline ImageView image_view(void* base, int W, int H)
     const size_t N = (size_t)W * (size_t)H;
     const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * (size_t)((H + TILE_Y - 1) / TILE_Y);
     v.zero_begin = cur;
-    carve(cur, v.ranges, T ? T : 1);
     carve(cur, v.tile_need, T ? T : 1);
     carve(cur, v.bwd_count, (size_t)4);
     v.zero_bytes = (size_t)(cur - v.zero_begin);
+    carve(cur, v.ranges, T ? T : 1);
     carve(cur, v.final_T, N ? N : 1);
     carve(cur, v.n_contrib, N ? N : 1);
     carve(cur, v.tile_order, T ? T : 1);
