@@ -31,8 +31,7 @@ struct DupArgs {
     int P;
     uint32_t gridx;
     const uint32_t* order;           // ids in depth order
-    const uint32_t* tiles_touched;
-    const uint2* rect;
+    const Splat* splat;              // q3 = (rect.x, rect.y, tiles touched, -) as written by k_preprocess
     uint64_t* dup_status;            // [nblk] zeroed before the launch; pair count + 1 once a workgroup has published
     uint64_t* counters;
     size_t g_stride;
@@ -54,16 +53,16 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int slot = blockIdx.x * DUP_THREADS + threadIdx.x;  // position in depth order
     const uint32_t* order = at_view(a.order, a.g_stride, view);
-    const uint32_t* tiles_touched = at_view(a.tiles_touched, a.g_stride, view);
-    const uint2* rect = at_view(a.rect, a.g_stride, view);
+    const Splat* splat = at_view(a.splat, a.g_stride, view);
     uint64_t* status = at_view(a.dup_status, a.g_stride, view);
 
     uint32_t cnt = 0, id = 0;
     uint2 rc = make_uint2(0, 0);
     if (slot < a.P) {
         id = order[slot];
-        cnt = tiles_touched[id];
-        rc = rect[id];
+        const float4 q3 = splat[id].q3;   // one 16-B gather: tile rectangle + tile count
+        rc = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
+        cnt = __float_as_uint(q3.z);
     }
     // ---- prefix sum: inside the wave, over the workgroup's waves, over the preceding workgroups ----
     uint32_t inc = cnt;   // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: wave sums are carried in 64 bits below
@@ -144,8 +143,7 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     a.P = P;
     a.gridx = (uint32_t)gridx;
     a.order = B.g.dval[0];
-    a.tiles_touched = B.g.tiles_touched;
-    a.rect = B.g.rect;
+    a.splat = B.g.splat;
     a.dup_status = B.g.dup_status;
     a.counters = B.g.counters;
     a.g_stride = B.g_stride;

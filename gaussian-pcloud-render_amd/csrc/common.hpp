@@ -49,7 +49,8 @@ __host__ __device__ __forceinline__ T* at_view(T* p, size_t stride_bytes, uint32
 
 // Per-Gaussian packed splat record: what the render kernels gather per list entry.  Padded to one 64-B cache line, so a
 // gather touches exactly one line (a 48-B record straddles two half of the time) and preprocess writes whole lines.
-//   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, depth, 0, 0)   q3 = padding
+//   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, depth, 0, 0)
+//   q3 = (tile rect min: x | y << 16, tile rect max: x | y << 16, tiles touched, -) as raw bits, for the pair emission
 struct __attribute__((aligned(64))) Splat {
     float4 q0, q1, q2, q3;
 };
@@ -69,7 +70,6 @@ constexpr int CNT_TRAP = 1;          // prefiltered = 1 but a Gaussian was culle
 struct GeomView {
     Splat* splat;             // [P]
     uint32_t* tiles_touched;  // [P]
-    uint2* rect;              // [P] x = minx | miny<<16, y = maxx | maxy<<16  (tile units)
     uint8_t* clamped;         // [P] bit k = colour channel k was clamped at 0 (CR/forward.cu:66-69)
     uint32_t* dkey[2];        // [P] depth-bit keys, ping-pong (dkey[0] is also preprocess' output)
     uint32_t* dval[2];        // [P] Gaussian ids, ping-pong; after 4 passes dval[0] = ids in depth order
@@ -134,7 +134,6 @@ inline GeomView geom_view(void* base, int P)
     const size_t nblk = (size_t)sort_hist_stride((int64_t)p);
     carve(cur, g.splat, p);
     carve(cur, g.tiles_touched, p);
-    carve(cur, g.rect, p);
     carve(cur, g.clamped, p);
     carve(cur, g.dkey[0], p);
     carve(cur, g.dkey[1], p);

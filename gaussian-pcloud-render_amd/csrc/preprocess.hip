@@ -69,7 +69,6 @@ struct PreArgs {
     const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
     Splat* splat;
     uint32_t* tiles_touched;
-    uint2* rect;
     uint8_t* clamped;
     uint32_t* dkey;
     float* grad_rec;
@@ -177,11 +176,13 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     a.radii[(size_t)vw * a.P + idx] = radius_out;
     at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
     at_view(a.dkey, a.g_stride, vw)[idx] = key;
-    at_view(a.rect, a.g_stride, vw)[idx] = rect;
     Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
-    sp->q0 = s.q0;   // (q3 is padding: never written, never read)
+    sp->q0 = s.q0;
     sp->q1 = s.q1;
     sp->q2 = s.q2;
+    // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
+    // Gaussian; the whole 64-B line is written here
+    sp->q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
     if (a.need_backward) {
         at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
         // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
@@ -207,7 +208,7 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.means3D = p.means3D; a.shs = p.shs; a.colors_precomp = p.colors_precomp; a.opacities = p.opacities;
     a.scales = p.scales; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
     a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
-    a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.rect = g.rect; a.clamped = g.clamped;
+    a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped;
     a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters; a.grad_rec = g.grad_rec;
     a.g_zero = g.zero_begin; a.g_zero_bytes = g.zero_bytes; a.g_stride = B.g_stride;
     a.iv_zero = B.iv.zero_begin; a.iv_zero_bytes = B.iv.zero_bytes; a.iv_stride = B.iv_stride;

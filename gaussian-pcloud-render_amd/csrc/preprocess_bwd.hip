@@ -56,6 +56,7 @@ template <int DEG> constexpr int sh_words() { return 3 * (DEG + 1) * (DEG + 1); 
 
 struct PreBwdArgs {
     int P, D, M, V;
+    int stage_sh;                        // dL_dsh rows go through LDS (256 x 3 M floats fit)
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
     const float *means3D, *shs, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
@@ -149,8 +150,9 @@ __device__ __forceinline__ V3 sh_backward(V3 pos, V3 campos, const float* __rest
 template <int DEG>
 __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [256][3 M] staging of the dL_dsh rows (a.stage_sh)
+    const bool active = blockIdx.x * 256 + threadIdx.x < (unsigned)a.P;
+    const int idx = active ? (int)(blockIdx.x * 256 + threadIdx.x) : a.P - 1;   // idle lanes of the last block shadow a real one
 
     // sums over the views of the batch
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
@@ -249,6 +251,30 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
         gmean = gmean + dmean;
     }
 
+    if (a.shs) {
+        // dL_dsh rows (3 M floats per Gaussian, only 3 (DEG+1)^2 of them non-zero): through LDS, so that the workgroup writes
+        // its 256 x 3 M floats as one contiguous, 16-B-per-lane stream instead of 3 M stride-12M scalar stores per lane
+        const int W3 = 3 * a.M;
+        if (a.stage_sh) {
+            float* row = s_rows + (size_t)threadIdx.x * W3;
+#pragma unroll
+            for (int i = 0; i < NSH; i++) row[i] = gsh[i];
+            for (int i = NSH; i < W3; i++) row[i] = 0.f;
+            __syncthreads();
+            const int rows = a.P - (int)blockIdx.x * 256 < 256 ? a.P - (int)blockIdx.x * 256 : 256;
+            const int total = rows * W3;
+            float* out = a.dL_dsh + (size_t)blockIdx.x * 256 * W3;   // 256 * 3 M floats per block: 16-B aligned
+            for (int j = 4 * (int)threadIdx.x; j + 3 < total; j += 4 * 256)
+                *reinterpret_cast<float4*>(out + j) = *reinterpret_cast<const float4*>(s_rows + j);
+            if ((int)threadIdx.x < (total & 3)) out[(total & ~3) + threadIdx.x] = s_rows[(total & ~3) + threadIdx.x];
+        } else if (active) {
+            float* out = a.dL_dsh + (size_t)idx * W3;
+#pragma unroll
+            for (int i = 0; i < NSH; i++) out[i] = gsh[i];
+            for (int i = NSH; i < W3; i++) out[i] = 0.f;
+        }
+    }
+    if (!active) return;
     a.dL_dmean2D[3 * (size_t)idx + 0] = g2x;
     a.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
     a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
@@ -261,12 +287,6 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     a.dL_dmean3D[3 * (size_t)idx + 2] = gmean.z;
 #pragma unroll
     for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gS[i];
-    if (a.shs) {
-        float* out = a.dL_dsh + (size_t)idx * a.M * 3;
-#pragma unroll
-        for (int i = 0; i < NSH; i++) out[i] = gsh[i];
-        for (int i = NSH; i < 3 * a.M; i++) out[i] = 0.f;
-    }
 
     // ---- 3D covariance -> scale, rotation (the sum over views entered gS linearly, so this runs once)
     if (a.scales) {
@@ -315,11 +335,14 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch
     a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
     const dim3 grid((p.P + 255) / 256), block(256);
+    size_t lds = p.shs ? (size_t)256 * 3 * p.M * sizeof(float) : 0;
+    a.stage_sh = lds != 0 && lds <= 64 * 1024;
+    if (!a.stage_sh) lds = 0;
     switch (p.shs ? p.D : 0) {
-    case 0: hipLaunchKernelGGL(k_preprocess_backward<0>, grid, block, 0, L.stream, a); break;
-    case 1: hipLaunchKernelGGL(k_preprocess_backward<1>, grid, block, 0, L.stream, a); break;
-    case 2: hipLaunchKernelGGL(k_preprocess_backward<2>, grid, block, 0, L.stream, a); break;
-    default: hipLaunchKernelGGL(k_preprocess_backward<3>, grid, block, 0, L.stream, a); break;
+    case 0: hipLaunchKernelGGL(k_preprocess_backward<0>, grid, block, lds, L.stream, a); break;
+    case 1: hipLaunchKernelGGL(k_preprocess_backward<1>, grid, block, lds, L.stream, a); break;
+    case 2: hipLaunchKernelGGL(k_preprocess_backward<2>, grid, block, lds, L.stream, a); break;
+    default: hipLaunchKernelGGL(k_preprocess_backward<3>, grid, block, lds, L.stream, a); break;
     }
     return check_launch(L, "preprocess_backward");
 }
