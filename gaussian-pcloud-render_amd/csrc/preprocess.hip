@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t clamp_tile(float f, uint32_t grid)
 }
 
 struct PreArgs {
-    int P, D, M, W, H;
+    int P, D, M, W, H, V, vpt;            // vpt: views per thread (grid.y = ceil(V / vpt))
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
     int prefiltered, need_backward;
     uint32_t gridx, gridy;
@@ -82,113 +82,120 @@ struct PreArgs {
 
 __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 {
-    const uint32_t vw = blockIdx.y;
+    // A thread owns one Gaussian for a.vpt consecutive views of the batch: the inputs (mean, scale / rotation -> 3D
+    // covariance, opacity, precomputed colour) are read and prepared ONCE, only the per-view part is repeated, so a batch of V
+    // views reads the cloud once instead of V times.
+    const int v_first = blockIdx.y * a.vpt, v_last = v_first + a.vpt < a.V ? v_first + a.vpt : a.V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    // this frame's bookkeeping that later kernels accumulate into (prefix-sum status words; tile ranges, consumed-entry
-    // counts, backward item count) is cleared here, so a frame needs no memset launches
+    // this frame's bookkeeping that later kernels accumulate into (prefix-sum status words; consumed-entry counts, backward
+    // item count) is cleared here, so a frame needs no memset launches
     {
         const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
-        zero_region(a.g_zero + a.g_stride * vw, a.g_zero_bytes, gtid, nthr);
-        zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
+        for (int vw = v_first; vw < v_last; vw++) {
+            zero_region(a.g_zero + a.g_stride * vw, a.g_zero_bytes, gtid, nthr);
+            zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
+        }
     }
     if (idx >= a.P) return;
 
-    // uniform data: 35 scalar loads, served by the scalar cache
-    float view[16], proj[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        view[i] = a.view[16 * vw + i];
-        proj[i] = a.proj[16 * vw + i];
-    }
-
-    int radius_out = 0;
-    uint32_t tiles = 0, key = 0xFFFFFFFFu, cmask = 0;
-    uint2 rect = make_uint2(0, 0);
-    Splat s;
-    s.q0 = make_float4(0, 0, 0, 0);
-    s.q1 = make_float4(0, 0, 0, 0);
-    s.q2 = make_float4(0, 0, 0, 0);
-
     const V3 p_orig = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-    const V3 p_view = xform_point_4x3(p_orig, view);
-
-    if (p_view.z <= 0.2f) {
-        if (a.prefiltered) at_view(a.counters, a.g_stride, vw)[CNT_TRAP] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
-    } else {
-        const float hx = ((proj[0] * p_orig.x + proj[4] * p_orig.y) + proj[8] * p_orig.z) + proj[12];
-        const float hy = ((proj[1] * p_orig.x + proj[5] * p_orig.y) + proj[9] * p_orig.z) + proj[13];
-        const float hw = ((proj[3] * p_orig.x + proj[7] * p_orig.y) + proj[11] * p_orig.z) + proj[15];
-        const float p_w = 1.0f / (hw + 0.0000001f);
-        const float proj_x = hx * p_w, proj_y = hy * p_w;
-
-        float cov6[6];
-        if (a.cov3D_precomp) {
+    float cov6[6];
+    if (a.cov3D_precomp) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
-        } else {
-            const V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
-            const float4 q = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
-            cov3d_from_scale_rot(sc, a.scale_modifier, q, cov6, nullptr);
+        for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+    } else {
+        const V3 sc = v3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+        const float4 q = *reinterpret_cast<const float4*>(a.rotations + 4 * (size_t)idx);
+        cov3d_from_scale_rot(sc, a.scale_modifier, q, cov6, nullptr);
+    }
+    const float opacity = a.opacities[idx];
+    V3 rgb_pre = v3(0, 0, 0);
+    if (a.colors_precomp) rgb_pre = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+
+    for (int vw = v_first; vw < v_last; vw++) {
+        // uniform data: 35 scalar loads, served by the scalar cache
+        float view[16], proj[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            view[i] = a.view[16 * vw + i];
+            proj[i] = a.proj[16 * vw + i];
         }
 
-        const Cov2D c = cov2d_project(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, cov6, view);
-        const float cov_x = c.cov.m[0][0] + 0.3f;  // dilation is ON in this fork (CR/forward.cu:112-113)
-        const float cov_y = c.cov.m[0][1];
-        const float cov_z = c.cov.m[1][1] + 0.3f;
+        int radius_out = 0;
+        uint32_t tiles = 0, key = 0xFFFFFFFFu, cmask = 0;
+        uint2 rect = make_uint2(0, 0);
+        Splat s;
+        s.q0 = make_float4(0, 0, 0, 0);
+        s.q1 = make_float4(0, 0, 0, 0);
+        s.q2 = make_float4(0, 0, 0, 0);
 
-        const float det = (cov_x * cov_z - cov_y * cov_y);
-        if (det != 0.0f) {
-            const float det_inv = 1.f / det;
-            const float conic_x = cov_z * det_inv, conic_y = -cov_y * det_inv, conic_z = cov_x * det_inv;
+        const V3 p_view = xform_point_4x3(p_orig, view);
+        if (p_view.z <= 0.2f) {
+            if (a.prefiltered) at_view(a.counters, a.g_stride, vw)[CNT_TRAP] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
+        } else {
+            const float hx = ((proj[0] * p_orig.x + proj[4] * p_orig.y) + proj[8] * p_orig.z) + proj[12];
+            const float hy = ((proj[1] * p_orig.x + proj[5] * p_orig.y) + proj[9] * p_orig.z) + proj[13];
+            const float hw = ((proj[3] * p_orig.x + proj[7] * p_orig.y) + proj[11] * p_orig.z) + proj[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float proj_x = hx * p_w, proj_y = hy * p_w;
 
-            const float mid = 0.5f * (cov_x + cov_z);
-            const float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
-            const float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
-            const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
-            const float px = ndc_to_pix(proj_x, a.W), py = ndc_to_pix(proj_y, a.H);
+            const Cov2D c = cov2d_project(p_orig, a.focal_x, a.focal_y, a.tanfovx, a.tanfovy, cov6, view);
+            const float cov_x = c.cov.m[0][0] + 0.3f;  // dilation is ON in this fork (CR/forward.cu:112-113)
+            const float cov_y = c.cov.m[0][1];
+            const float cov_z = c.cov.m[1][1] + 0.3f;
 
-            // getRect (CR/auxiliary.h:46-56); max_radius is an int there
-            const float r = (float)(int)my_radius;
-            const uint32_t minx = clamp_tile((px - r) / (float)TILE_X, a.gridx);
-            const uint32_t miny = clamp_tile((py - r) / (float)TILE_Y, a.gridy);
-            const uint32_t maxx = clamp_tile((((px + r) + (float)TILE_X) - 1.0f) / (float)TILE_X, a.gridx);
-            const uint32_t maxy = clamp_tile((((py + r) + (float)TILE_Y) - 1.0f) / (float)TILE_Y, a.gridy);
-            const uint32_t ntiles = (maxx - minx) * (maxy - miny);
-            if (ntiles != 0) {
-                V3 rgb;
-                if (a.colors_precomp) {
-                    rgb = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
-                } else {
-                    const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
-                    rgb = sh_to_rgb(a.D, p_orig, cam, a.shs + (size_t)idx * a.M * 3, &cmask);
+            const float det = (cov_x * cov_z - cov_y * cov_y);
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float conic_x = cov_z * det_inv, conic_y = -cov_y * det_inv, conic_z = cov_x * det_inv;
+
+                const float mid = 0.5f * (cov_x + cov_z);
+                const float lambda1 = mid + sqrtf(fmax_(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(fmax_(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+                const float px = ndc_to_pix(proj_x, a.W), py = ndc_to_pix(proj_y, a.H);
+
+                // getRect (CR/auxiliary.h:46-56); max_radius is an int there
+                const float r = (float)(int)my_radius;
+                const uint32_t minx = clamp_tile((px - r) / (float)TILE_X, a.gridx);
+                const uint32_t miny = clamp_tile((py - r) / (float)TILE_Y, a.gridy);
+                const uint32_t maxx = clamp_tile((((px + r) + (float)TILE_X) - 1.0f) / (float)TILE_X, a.gridx);
+                const uint32_t maxy = clamp_tile((((py + r) + (float)TILE_Y) - 1.0f) / (float)TILE_Y, a.gridy);
+                const uint32_t ntiles = (maxx - minx) * (maxy - miny);
+                if (ntiles != 0) {
+                    V3 rgb = rgb_pre;
+                    if (!a.colors_precomp) {
+                        const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
+                        rgb = sh_to_rgb(a.D, p_orig, cam, a.shs + (size_t)idx * a.M * 3, &cmask);
+                    }
+                    radius_out = (int)my_radius;
+                    tiles = ntiles;
+                    key = __float_as_uint(p_view.z);
+                    rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
+                    s.q0 = make_float4(px, py, conic_x, conic_y);
+                    s.q1 = make_float4(conic_z, opacity, rgb.x, rgb.y);
+                    s.q2 = make_float4(rgb.z, p_view.z, 0.f, 0.f);
                 }
-                radius_out = (int)my_radius;
-                tiles = ntiles;
-                key = __float_as_uint(p_view.z);
-                rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
-                s.q0 = make_float4(px, py, conic_x, conic_y);
-                s.q1 = make_float4(conic_z, a.opacities[idx], rgb.x, rgb.y);
-                s.q2 = make_float4(rgb.z, p_view.z, 0.f, 0.f);
             }
         }
-    }
 
-    a.radii[(size_t)vw * a.P + idx] = radius_out;
-    at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
-    at_view(a.dkey, a.g_stride, vw)[idx] = key;
-    Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
-    sp->q0 = s.q0;
-    sp->q1 = s.q1;
-    sp->q2 = s.q2;
-    // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
-    // Gaussian; the whole 64-B line is written here
-    sp->q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
-    if (a.need_backward) {
-        at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
-        // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
-        float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.g_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
+        a.radii[(size_t)vw * a.P + idx] = radius_out;
+        at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
+        at_view(a.dkey, a.g_stride, vw)[idx] = key;
+        Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
+        sp->q0 = s.q0;
+        sp->q1 = s.q1;
+        sp->q2 = s.q2;
+        // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
+        // Gaussian; the whole 64-B line is written here
+        sp->q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
+        if (a.need_backward) {
+            at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
+            // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
+            float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.g_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
+        }
     }
 }
 
@@ -213,7 +220,13 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.g_zero = g.zero_begin; a.g_zero_bytes = g.zero_bytes; a.g_stride = B.g_stride;
     a.iv_zero = B.iv.zero_begin; a.iv_zero_bytes = B.iv.zero_bytes; a.iv_stride = B.iv_stride;
     const int blocks = (p.P + 255) / 256;
-    hipLaunchKernelGGL(k_preprocess, dim3(blocks, B.V), dim3(256), 0, L.stream, a);
+    // all views of a Gaussian in one thread when the cloud alone fills the chip (256 CUs x 8 workgroups), otherwise the views
+    // are spread over grid.y so that small clouds keep their parallelism
+    a.V = B.V;
+    a.vpt = 1;
+    while (a.vpt < B.V && (int64_t)blocks * div_up(B.V, a.vpt * 2) >= 2048) a.vpt *= 2;
+    if (a.vpt > B.V) a.vpt = B.V;
+    hipLaunchKernelGGL(k_preprocess, dim3(blocks, (unsigned)div_up(B.V, a.vpt)), dim3(256), 0, L.stream, a);
     return check_launch(L, "preprocess");
 }
 

@@ -340,8 +340,9 @@ _QSPEC = {
 }
 
 
-def query(name, P, W, H, R, geom, binning, img):
-    """Copy one private arena array out (device tensor).  Unsigned data come back in same-width signed dtypes."""
+def query(name, P, W, H, R, geom, binning, img, view=0, n_views=1):
+    """Copy one private arena array of `view` out of the arenas of an `n_views` batch (device tensor).  Unsigned data come
+    back in same-width signed dtypes."""
     dtype, shp = _QSPEC[name]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     out = torch.zeros(shp(P, R, T, W * H), dtype=dtype, device=geom.device)
@@ -349,9 +350,16 @@ def query(name, P, W, H, R, geom, binning, img):
         return out
     p = GsrParams()
     p.P, p.W, p.H = P, W, H
+    # view v's arenas start v strides into the allocations (include/gsr.h: V identically laid out single-view arenas)
+    g_stride, i_stride = lib.gsr_geom_bytes(P) - 256, lib.gsr_image_bytes(W, H) - 256
+    b_stride = ((binning.numel() - 256) // n_views) // 256 * 256 if binning.numel() else 0
+    if geom.data_ptr() % 256 or img.data_ptr() % 256 or (binning.numel() and binning.data_ptr() % 256):
+        raise RuntimeError("query: arena base pointers are expected to be 256-byte aligned")
     with torch.cuda.device(geom.device):
-        _check(lib.gsr_query(C.byref(p), Q[name], geom.data_ptr(), _ptr(binning), binning.numel(), img.data_ptr(), int(R),
-                             out.data_ptr(), out.numel() * out.element_size(), torch.cuda.current_stream(geom.device).cuda_stream))
+        _check(lib.gsr_query(C.byref(p), Q[name], geom.data_ptr() + view * g_stride,
+                             (binning.data_ptr() + view * b_stride) if binning.numel() else None, b_stride + 256,
+                             img.data_ptr() + view * i_stride, int(R), out.data_ptr(), out.numel() * out.element_size(),
+                             torch.cuda.current_stream(geom.device).cuda_stream))
     return out
 
 

@@ -75,13 +75,19 @@ def test_batch_equals_single_view_calls_bit_for_bit(gpu_device):
     dev = gpu_device
     g, views, W, H = _views_scene(5, P=20000, W=320, H=240)
     args = _batch_args(g, views, W, H, dev)
-    counts, color, radii, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)
+    counts, color, radii, geom, binning, img = N.rasterize_gaussians_batch(*args, need_backward=False)
+    P, V = g["means3D"].shape[0], len(views)
     for v, view in enumerate(views):
         one = list(args)
         one[8], one[9], one[16] = args[8][v], args[9][v], args[16][v]
-        R, c1, r1, *_ = N.rasterize_gaussians(*one, need_backward=False)
+        R, c1, r1, g1, b1, i1 = N.rasterize_gaussians(*one, need_backward=False)
         assert R == counts[v]
         assert torch.equal(c1, color[v]) and torch.equal(r1, radii[v])
+        # the private arrays of view v inside the batch arenas: sorted lists, ranges, per-pixel bookkeeping
+        for name in ("POINT_LIST", "POINT_LIST_KEYS", "RANGES", "N_CONTRIB", "FINAL_T", "TILES_TOUCHED"):
+            a = N.query(name, P, W, H, R, geom, binning, img, view=v, n_views=V)
+            b = N.query(name, P, W, H, R, g1, b1, i1)
+            assert torch.equal(a, b), (v, name)
 
 
 def test_too_small_arena_is_retried_transparently(gpu_device):
