@@ -322,8 +322,8 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
 }
 
 // Colour-only re-render on the geometry / lists of a finished forward (same P, views, image size).
-int gsr_forward_recolor(const gsr_params* p, int V, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes, void* image,
-                        size_t image_bytes, float* out_color, gsr_stream_t stream)
+int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* geom, size_t geom_bytes, const void* binning,
+                        size_t binning_bytes, void* image, size_t image_bytes, float* out_color, gsr_stream_t stream)
 {
     if (!p) return fail(GSR_ERR_INVALID, "[gsr] params is NULL");
     if (V < 1 || V > MAX_VIEWS) return fail(GSR_ERR_INVALID, "[gsr] view count %d outside 1..%d", V, MAX_VIEWS);
@@ -339,7 +339,7 @@ int gsr_forward_recolor(const gsr_params* p, int V, void* geom, size_t geom_byte
     const int res = sorted_buffer(tile_count(p));
     {
         ProfScope ps("recolor", L.stream);
-        if (int e = launch_recolor(L, *p, B)) return e;
+        if (int e = launch_recolor(L, *p, B, (colors_per_view && p->colors_precomp) ? (size_t)p->P * 3 : 0)) return e;
         // the render accumulates the consumed-entry counts from zero
         if (int e = memset_views(L.stream, B.iv.tile_need, B.iv_stride, (size_t)tile_count(p) * sizeof(uint32_t), V)) return e;
     }

@@ -234,7 +234,7 @@ int check_launch(const Launch& L, const char* what);  // api.hip
 
 // preprocess.hip
 int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int* radii);
-int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B);
+int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B, size_t colors_view_stride);
 int launch_mark_visible(const Launch& L, int P, const float* means3D, const float* view, uint8_t* present);
 // sort.hip
 // Stable LSD radix sort of `V` independent (u32 key, u32 value) problems laid out at `stride` bytes from each other.

@@ -239,9 +239,10 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
 __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const float* __restrict__ means3D,
                                                  const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                                                  const float* __restrict__ campos, const uint32_t* __restrict__ tiles_touched,
-                                                 Splat* __restrict__ splat, size_t g_stride)
+                                                 Splat* __restrict__ splat, size_t g_stride, size_t colors_view_stride)
 {
     const uint32_t vw = blockIdx.y;
+    if (colors_precomp) colors_precomp += colors_view_stride * vw;
     tiles_touched = at_view(tiles_touched, g_stride, vw);
     splat = at_view(splat, g_stride, vw);
     if (campos) campos += 3 * vw;
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const floa
     rec[8] = rgb.z;  // q2.x
 }
 
-int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B)
+int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B, size_t colors_view_stride)
 {
     hipLaunchKernelGGL(k_recolor, dim3((p.P + 255) / 256, B.V), dim3(256), 0, L.stream, p.P, p.D, p.M, p.means3D, p.shs,
-                       p.colors_precomp, p.campos, B.g.tiles_touched, B.g.splat, B.g_stride);
+                       p.colors_precomp, p.campos, B.g.tiles_touched, B.g.splat, B.g_stride, colors_view_stride);
     return check_launch(L, "recolor");
 }
 

@@ -82,14 +82,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
         if (d <= mask) hist[(size_t)d * nblk_pad + blockIdx.x] = 0;
         return;
     }
-    // HIST_COPIES private histograms (two per wave, by lane parity): same-digit keys of one wave instruction serialise in
-    // the LDS atomic unit, the copies halve those collisions
-    constexpr int HIST_COPIES = 2 * RS_WAVES;
+    // HIST_COPIES private histograms (four per wave, by lane mod 4): same-digit keys of one wave instruction serialise in
+    // the LDS atomic unit, the copies quarter those collisions
+    constexpr int HIST_COPIES = 4 * RS_WAVES;
     __shared__ uint32_t h[HIST_COPIES][RADIX];
     for (int i = threadIdx.x; i < HIST_COPIES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
-    const uint32_t w = (threadIdx.x >> 6) * 2u + (threadIdx.x & 1u);
+    const uint32_t w = (threadIdx.x >> 6) * 4u + (threadIdx.x & 3u);
     if (sizeof(KeyT) == 2 && base + RS_TILE <= n) {
         // full block of 16-bit keys: two 16-B loads per thread instead of sixteen 2-B ones (counting is order-free)
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base) + threadIdx.x * 2;

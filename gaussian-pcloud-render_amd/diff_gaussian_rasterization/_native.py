@@ -62,7 +62,8 @@ def _load():
     lib.gsr_forward_stage2.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
                                        C.c_int64, _fp, _fp]
     lib.gsr_forward_recolor.restype = C.c_int
-    lib.gsr_forward_recolor.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp]
+    lib.gsr_forward_recolor.argtypes = [C.POINTER(GsrParams), C.c_int, C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp,
+                                        _fp]
     lib.gsr_backward_batch.restype = C.c_int
     lib.gsr_backward_batch.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, _fp, C.c_size_t, _fp, C.c_size_t, _fp,
                                        C.c_size_t] + [_fp] * 9 + [_fp]
@@ -237,9 +238,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def recolor(background, means3D, colors, sh, degree, campos, image_height, image_width, num_rendered, geomBuffer,
             binningBuffer, imgBuffer, debug=False):
-    """Re-render a finished forward's view(s) with other per-Gaussian colours (exactly one of `colors` [P,3] / `sh`
-    [P,M,3] non-empty), reusing its geometry, sorted lists and ranges (gsr_forward_recolor).  campos [3] -> color [3,H,W];
-    campos [V,3] (a batch forward's arenas) -> [V,3,H,W]."""
+    """Re-render a finished forward's view(s) with other per-Gaussian colours (exactly one of `colors` / `sh` [P,M,3]
+    non-empty), reusing its geometry, sorted lists and ranges (gsr_forward_recolor).  campos [3] -> color [3,H,W];
+    campos [V,3] (a batch forward's arenas) -> [V,3,H,W], with `colors` [P,3] shared by the views or [V,P,3] per view."""
     device = means3D.device
     _require_hip(device)
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
@@ -252,7 +253,10 @@ def recolor(background, means3D, colors, sh, degree, campos, image_height, image
             p, keep = _params(background, means3D, colors, torch.empty((1,), device=device), e, e, 1.0, e,
                               torch.empty((1,), device=device), torch.empty((1,), device=device), 1.0, 1.0, H, W, sh, degree,
                               campos, False, debug, False)
-            _check(lib.gsr_forward_recolor(C.byref(p), V, geomBuffer.data_ptr(), geomBuffer.numel(), binningBuffer.data_ptr(),
+            per_view = int(colors.numel() != 0 and colors.dim() == 3)
+            if per_view and tuple(colors.shape) != (V, P, 3):
+                raise RuntimeError("recolor: per-view colours must have shape (V, P, 3)")
+            _check(lib.gsr_forward_recolor(C.byref(p), V, per_view, geomBuffer.data_ptr(), geomBuffer.numel(), binningBuffer.data_ptr(),
                                            binningBuffer.numel(), imgBuffer.data_ptr(), imgBuffer.numel(),
                                            out_color.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
             del keep

@@ -8,9 +8,9 @@ Mirrors, for inference use (the reference calls these under torch.no_grad(), sim
 bilinear down-filter when super_sample_rate > 1, permute to (b, q, h, w, 3).
 
 `render_passes` produces the same four images per view but runs the geometry (preprocess, depth sort, pair
-emission, tile sort, ranges) ONCE per view and re-renders the other colours on it with
-diff_gaussian_rasterization._native.recolor (C ABI gsr_forward_recolor); every pass is bit-identical to the
-corresponding full call.
+emission, tile sort, ranges) ONCE per view -- all views in one submission (C ABI gsr_forward_batch) -- and re-renders the
+other colours on it with diff_gaussian_rasterization._native.recolor (C ABI gsr_forward_recolor), again all views per
+call; every pass is bit-identical to the corresponding full call.
 """
 import math
 
@@ -73,32 +73,36 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
     """The four passes of PCML_Render.render for ONE cloud and q views (H_c2w [q,4,4]); returns a dict of
     (1, q, h, w, 3) tensors: 'rgb', 'xyz_w', 'hitmap' and 'normal' (None without normals).
 
-    Per view the pipeline front end runs once (with the SH colours); xyz, ones and normals are re-rendered on the same
-    sorted lists.  Inference only (no autograd graph), like the reference's use."""
+    All q views go through the pipeline front end in ONE submission (gsr_forward_batch, with the SH colours); xyz, ones and
+    the normals are re-rendered on the same sorted lists, again all views per call (the normals with per-view colours: the
+    reference flips their sign view by view).  Inference only (no autograd graph), like the reference's use."""
     device = means3D.device
     num_q = H_c2w.shape[0]
     radius = float(np.sqrt(3) / scale_factor * 6)
     sc = (scales * radius).contiguous()
-    ones = torch.ones_like(means3D)
-    out = {"rgb": [], "xyz_w": [], "hitmap": [], "normal": [] if normals is not None else None}
     e = torch.empty(0)
-    colors_n = normals
-    for j in range(num_q):
-        st = settings_for_view(H_c2w[j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
-        H, W = st.image_height, st.image_width
-        R, rgb, radii, geom, binning, img = _native.rasterize_gaussians(
-            st.bg, means3D, e, opacities, sc, rotations, 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, H, W,
-            shs, sh_degree, st.campos, False, False, need_backward=False)
-        out["rgb"].append(rgb)
+    sts = [settings_for_view(H_c2w[j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
+           for j in range(num_q)]
+    st = sts[0]
+    H, W = st.image_height, st.image_width
+    view = torch.stack([s.viewmatrix.reshape(4, 4) for s in sts]).contiguous()
+    proj = torch.stack([s.projmatrix.reshape(4, 4) for s in sts]).contiguous()
+    cam = torch.stack([s.campos.reshape(3) for s in sts]).contiguous()
+    counts, rgb, radii, geom, binning, img = _native.rasterize_gaussians_batch(
+        st.bg, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, st.tanfovx, st.tanfovy, H, W, shs, sh_degree, cam, False,
+        False, need_backward=False)
 
-        def again(colors):
-            return _native.recolor(st.bg, means3D, colors, e, 0, st.campos, H, W, R, geom, binning, img)
+    def again(colors):
+        return _native.recolor(st.bg, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
 
-        out["xyz_w"].append(again(means3D))
-        out["hitmap"].append(again(ones))
-        if normals is not None:
+    out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)), "normal": None}
+    if normals is not None:
+        per_view = []
+        colors_n = normals
+        for j in range(num_q):
             cam_orig = H_c2w[j, :3, 3].to(device)
             sgn = (torch.sum((means3D - cam_orig) * colors_n, -1, keepdim=True) > 0).float() * 2 - 1
             colors_n = colors_n * (-1) * sgn[0]          # carried across views exactly like the reference's loop
-            out["normal"].append(again(colors_n.contiguous()))
-    return {k: (None if v is None else _finish(v, 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}
+            per_view.append(colors_n)
+        out["normal"] = again(torch.stack(per_view, 0).contiguous())
+    return {k: (None if v is None else _finish(list(v), 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}

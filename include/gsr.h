@@ -117,11 +117,12 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
 /* Colour-only re-render.  The reference's caller renders four passes per view that differ only in the
  * per-Gaussian colour (world xyz / SH colour / ones / normals, simple_raw_render.py:410-524), each through the whole
  * pipeline.  After a forward this entry re-renders the same V views with other colours on the SAME geometry, lists and
- * ranges: p->colors_precomp [P,3] (verbatim) or p->shs (evaluated like the forward does); only P, D, M, W, H, bg, means3D,
+ * ranges: p->colors_precomp (verbatim; [P,3] shared by the views, or [V,P,3] with colors_per_view != 0 -- the reference's
+ * normal pass flips the normals' sign per view) or p->shs (evaluated like the forward does); only P, D, M, W, H, bg, means3D,
  * shs / colors_precomp, campos of *p are read.  The result is bit-identical to a full forward with those colours.  The
  * arenas stay valid for further recolor calls; a backward afterwards differentiates the LAST colours rendered. */
-int gsr_forward_recolor(const gsr_params* p, int V, void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
-                        void* image, size_t image_bytes, float* out_color, gsr_stream_t stream);
+int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* geom, size_t geom_bytes, const void* binning,
+                        size_t binning_bytes, void* image, size_t image_bytes, float* out_color, gsr_stream_t stream);
 
 /* Backward of a batch (rasterize_points.cu:117-196 / Rasterizer::backward rasterizer.h:61-90).  dL_dpix is [V,3,H,W]; the
  * per-Gaussian gradients are SUMMED over the V views (what autograd does with the reference's per-view calls on a shared
