@@ -49,12 +49,20 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     __shared__ uint2 s_rect[4][64];
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_base;
+    __shared__ uint32_t s_ticket;
     const uint32_t view = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int slot = blockIdx.x * DUP_THREADS + threadIdx.x;  // position in depth order
+    uint64_t* status = at_view(a.dup_status, a.g_stride, view);
+    // Which 256 Gaussians this workgroup takes is decided by a ticket drawn when it STARTS: a workgroup with a lower number
+    // has started earlier, so the look-back below only ever waits for workgroups that are already running or done, whatever
+    // order the hardware dispatches blockIdx in (HIP promises none).  The ticket word follows the status words.
+    const uint32_t nblk = gridDim.x;
+    if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long*)&status[nblk], 1ull);
+    __syncthreads();
+    const uint32_t blk = s_ticket;
+    const int slot = (int)(blk * DUP_THREADS + threadIdx.x);  // position in depth order
     const uint32_t* order = at_view(a.order, a.g_stride, view);
     const Splat* splat = at_view(a.splat, a.g_stride, view);
-    uint64_t* status = at_view(a.dup_status, a.g_stride, view);
 
     uint32_t cnt = 0, id = 0;
     uint2 rc = make_uint2(0, 0);
@@ -80,11 +88,11 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     for (int i = 0; i < 4; i++)
         if ((uint32_t)i < w) wave_base += s_wave[i];
     const uint64_t block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (threadIdx.x == 0) agent_store(&status[blockIdx.x], block_total + 1);
+    if (threadIdx.x == 0) agent_store(&status[blk], block_total + 1);
     // look-back: every preceding workgroup's count (published as count + 1; 0 = not yet).  They were dispatched before
     // this one, so waiting for them cannot deadlock.
     uint64_t part = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += DUP_THREADS) {
+    for (uint32_t b = threadIdx.x; b < blk; b += DUP_THREADS) {
         uint64_t v;
         do { v = agent_load(&status[b]); } while (v == 0);
         part += v - 1;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     if (threadIdx.x == 0) {
         const uint64_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         s_base = base;
-        if (blockIdx.x == gridDim.x - 1) at_view(a.counters, a.g_stride, view)[CNT_NUM_RENDERED] = base + block_total;
+        if (blk == nblk - 1) at_view(a.counters, a.g_stride, view)[CNT_NUM_RENDERED] = base + block_total;
     }
     __syncthreads();
     if (a.keys == nullptr) return;   // count-only call (no binning arena yet)

@@ -76,7 +76,7 @@ struct GeomView {
     uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts (depth sort)
     uint32_t* totals;         // [RADIX]
     float* grad_rec;          // [P][GRAD_REC_WORDS]
-    uint64_t* dup_status;     // [ceil(P / DUP_THREADS)] pair count + 1 of each emission workgroup (binning.hip look-back)
+    uint64_t* dup_status;     // [ceil(P / DUP_THREADS) + 1] pair count + 1 of each emission workgroup, then the ticket counter
     uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
     char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
     size_t zero_bytes;
@@ -143,7 +143,7 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.totals, (size_t)RADIX);
     carve(cur, g.grad_rec, p * GRAD_REC_WORDS);
     g.zero_begin = cur;
-    carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS));
+    carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS) + 1);   // + the ticket counter
     g.zero_bytes = (size_t)(cur - g.zero_begin);
     carve(cur, g.counters, (size_t)8);
     g.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
