@@ -13,17 +13,18 @@ namespace gsr {
 
 // SH -> RGB, reference CR/forward.cu:20-71.  `sh` points at this Gaussian's first coefficient
 // (stride M rows of 3 floats; only (deg+1)^2 rows are read).
-__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t* clamp_mask)
+template <int deg>
+__device__ __forceinline__ V3 sh_to_rgb_t(V3 pos, V3 campos, const float* sh, uint32_t* clamp_mask)
 {
     V3 dir = pos - campos;
     const float len = sqrtf(dot3(dir, dir));
     dir = v3(dir.x / len, dir.y / len, dir.z / len);
 #define SHV(k) v3(sh[3 * (k)], sh[3 * (k) + 1], sh[3 * (k) + 2])
     V3 result = kSH_C0 * SHV(0);
-    if (deg > 0) {
+    if constexpr (deg > 0) {
         const float x = dir.x, y = dir.y, z = dir.z;
         result = ((result - (kSH_C1 * y) * SHV(1)) + (kSH_C1 * z) * SHV(2)) - (kSH_C1 * x) * SHV(3);
-        if (deg > 1) {
+        if constexpr (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z;
             const float xy = x * y, yz = y * z, xz = x * z;
             result = result + (kSH_C2[0] * xy) * SHV(4);
@@ -31,7 +32,7 @@ __device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float*
             result = result + (kSH_C2[2] * (2.0f * zz - xx - yy)) * SHV(6);
             result = result + (kSH_C2[3] * xz) * SHV(7);
             result = result + (kSH_C2[4] * (xx - yy)) * SHV(8);
-            if (deg > 2) {
+            if constexpr (deg > 2) {
                 result = result + (kSH_C3[0] * y * (3.0f * xx - yy)) * SHV(9);
                 result = result + (kSH_C3[1] * xy * z) * SHV(10);
                 result = result + (kSH_C3[2] * y * (4.0f * zz - xx - yy)) * SHV(11);
@@ -48,6 +49,17 @@ __device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float*
     result.z += 0.5f;
     *clamp_mask = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
     return v3(fmax_(result.x, 0.0f), fmax_(result.y, 0.0f), fmax_(result.z, 0.0f));
+}
+
+// runtime-degree front end (k_recolor)
+__device__ __forceinline__ V3 sh_to_rgb(int deg, V3 pos, V3 campos, const float* __restrict__ sh, uint32_t* clamp_mask)
+{
+    switch (deg) {
+    case 0: return sh_to_rgb_t<0>(pos, campos, sh, clamp_mask);
+    case 1: return sh_to_rgb_t<1>(pos, campos, sh, clamp_mask);
+    case 2: return sh_to_rgb_t<2>(pos, campos, sh, clamp_mask);
+    default: return sh_to_rgb_t<3>(pos, campos, sh, clamp_mask);
+    }
 }
 
 // (v+1)*S-1)/2 evaluated in double, rounded once (reference CR/auxiliary.h:41-44)
@@ -80,6 +92,9 @@ struct PreArgs {
     int* radii;                           // [V][P]
 };
 
+// DEG = active SH degree (template parameter: the 3 (DEG+1)^2 coefficients a Gaussian needs are read ONCE into registers and
+// reused for every view of the batch -- re-reading them per view pulled the 156-B-stride SH rows from HBM five times over)
+template <int DEG>
 __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 {
     // A thread owns one Gaussian for a.vpt consecutive views of the batch: the inputs (mean, scale / rotation -> 3D
@@ -110,7 +125,15 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     }
     const float opacity = a.opacities[idx];
     V3 rgb_pre = v3(0, 0, 0);
-    if (a.colors_precomp) rgb_pre = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+    constexpr int NSH = 3 * (DEG + 1) * (DEG + 1);
+    float shv[NSH];
+    if (a.colors_precomp) {
+        rgb_pre = v3(a.colors_precomp[3 * idx], a.colors_precomp[3 * idx + 1], a.colors_precomp[3 * idx + 2]);
+    } else {
+        const float* shp = a.shs + (size_t)idx * a.M * 3;
+#pragma unroll
+        for (int i = 0; i < NSH; i++) shv[i] = shp[i];
+    }
 
     for (int vw = v_first; vw < v_last; vw++) {
         // uniform data: 35 scalar loads, served by the scalar cache
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                     V3 rgb = rgb_pre;
                     if (!a.colors_precomp) {
                         const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
-                        rgb = sh_to_rgb(a.D, p_orig, cam, a.shs + (size_t)idx * a.M * 3, &cmask);
+                        rgb = sh_to_rgb_t<DEG>(p_orig, cam, shv, &cmask);
                     }
                     radius_out = (int)my_radius;
                     tiles = ntiles;
@@ -226,7 +249,13 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.vpt = 1;
     while (a.vpt < B.V && (int64_t)blocks * div_up(B.V, a.vpt * 2) >= 2048) a.vpt *= 2;
     if (a.vpt > B.V) a.vpt = B.V;
-    hipLaunchKernelGGL(k_preprocess, dim3(blocks, (unsigned)div_up(B.V, a.vpt)), dim3(256), 0, L.stream, a);
+    const dim3 grid(blocks, (unsigned)div_up(B.V, a.vpt));
+    switch (p.shs ? p.D : 0) {
+    case 0: hipLaunchKernelGGL(k_preprocess<0>, grid, dim3(256), 0, L.stream, a); break;
+    case 1: hipLaunchKernelGGL(k_preprocess<1>, grid, dim3(256), 0, L.stream, a); break;
+    case 2: hipLaunchKernelGGL(k_preprocess<2>, grid, dim3(256), 0, L.stream, a); break;
+    default: hipLaunchKernelGGL(k_preprocess<3>, grid, dim3(256), 0, L.stream, a); break;
+    }
     return check_launch(L, "preprocess");
 }
 

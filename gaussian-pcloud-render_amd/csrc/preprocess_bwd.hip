@@ -71,7 +71,7 @@ struct PreBwdArgs {
 // SH backward (reference CR/backward.cu:20-139): adds this view's dL_dsh rows into acc, returns the mean gradient through the
 // normalised view direction.
 template <int deg>
-__device__ __forceinline__ V3 sh_backward(V3 pos, V3 campos, const float* __restrict__ sh, uint32_t cmask, V3 dL_dRGB,
+__device__ __forceinline__ V3 sh_backward(V3 pos, V3 campos, const float* sh, uint32_t cmask, V3 dL_dRGB,
                                           float (&acc)[sh_words<deg>()])
 {
     const V3 dir_orig = pos - campos;
@@ -177,6 +177,14 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
         cov3d_from_scale_rot(sc, a.scale_modifier, q, S6, nullptr);
     }
 
+    // the SH coefficients the view-direction term needs: read once, reused for every view
+    float shv[NSH];
+    if (a.shs) {
+        const float* shp = a.shs + (size_t)idx * a.M * 3;
+#pragma unroll
+        for (int i = 0; i < NSH; i++) shv[i] = shp[i];
+    }
+
     for (int vw = 0; vw < a.V; vw++) {
         // the render-level sums of this Gaussian in this view: one 64-B record (zeros when nothing was accumulated)
         const float* recp = at_view(a.grad_rec, a.g_stride, (uint32_t)vw) + (size_t)idx * GRAD_REC_WORDS;
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
         if (a.shs) {
             const V3 cam = v3(a.campos[3 * vw], a.campos[3 * vw + 1], a.campos[3 * vw + 2]);
             const uint8_t cm = at_view(a.clamped, a.g_stride, (uint32_t)vw)[idx];
-            dmean = dmean + sh_backward<DEG>(mean, cam, a.shs + (size_t)idx * a.M * 3, cm, v3(rec1.y, rec1.z, rec1.w), gsh);
+            dmean = dmean + sh_backward<DEG>(mean, cam, shv, cm, v3(rec1.y, rec1.z, rec1.w), gsh);
         }
         gmean = gmean + dmean;
     }
