@@ -168,3 +168,45 @@ def test_no_host_sync_between_kernels_of_a_frame(gpu_device):
     c2, img2, _, _, binning, _ = N.rasterize_gaussians_batch(*args, need_backward=False)   # second: one submission
     assert c2 == c1 and torch.equal(img1, img2)
     assert binning.numel() >= N.lib.gsr_binning_bytes(int(c1[0] * N.CAP_SLACK))
+
+
+def test_batch_edge_cases_vs_oracle(oracle, gpu_device):
+    """Small clouds with many views (views spread over grid.y in the preprocess kernel), a view that sees nothing
+    (num_rendered = 0: pure background), an empty cloud, and the maximum view count check."""
+    from diff_gaussian_rasterization import _native as N
+    from pcrender import camera, synth
+    dev = gpu_device
+    W, H = 72, 56
+    g = synth.random_scene(60, W, H, seed=3, sh_degree=2, spread=0.8, scale=0.1)
+    g["means3D"][:, 2] -= 3.0                                   # around the origin, like the circle cameras expect
+    views = camera.circle_views(12, fov_deg=45.0, width_px=W, height_px=H)
+    far = dict(views[0])
+    far["viewmatrix"] = views[0]["viewmatrix"].clone()
+    far["viewmatrix"][3, 2] = -50.0                             # camera-space z = z - 50: everything behind the near plane
+    vs = views[:9] + [far] + views[9:] + views[:4]              # 17 views
+    args = _batch_args(g, vs, W, H, dev, bg=(0.2, 0.5, 0.7))
+    counts, color, radii, geom, binning, img = N.rasterize_gaussians_batch(*args, need_backward=True)
+    assert counts[9] == 0 and int(radii[9].abs().max()) == 0
+    bgimg = torch.tensor([0.2, 0.5, 0.7], device=dev).view(3, 1, 1).expand(3, H, W)
+    assert torch.allclose(color[9], bgimg)
+    for v in (0, 5, 9, 16):
+        s = util.scene_from(g, vs[v], W, H, bg=(0.2, 0.5, 0.7))
+        o = oracle.forward(s)
+        assert counts[v] == o["R"]
+        np.testing.assert_array_equal(radii[v].cpu().numpy(), o["radii"])
+        err = np.abs(color[v].cpu().numpy() - o["out_color"]).max()
+        assert err <= 1e-4, (v, err)
+    dL = torch.ones_like(color)
+    grads = N.rasterize_gaussians_backward_batch(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9],
+                                                 args[10], args[11], dL, args[14], args[15], args[16], geom, binning, img, False)
+    assert all(torch.isfinite(x).all() for x in grads)
+    # empty cloud: zero images (not the background), like the reference's P == 0 shortcut
+    e = torch.empty(0)
+    z = torch.zeros((0, 3), device=dev)
+    cnt0, col0, rad0, *_ = N.rasterize_gaussians_batch(args[0], z, e, torch.zeros((0, 1), device=dev), z, torch.zeros((0, 4), device=dev),
+                                                      1.0, e, args[8][:3], args[9][:3], args[10], args[11], H, W,
+                                                      torch.zeros((0, 9, 3), device=dev), 2, args[16][:3], False, False)
+    assert cnt0 == [0, 0, 0] and not col0.any() and rad0.shape == (3, 0)
+    with pytest.raises(RuntimeError, match="view count"):
+        N.rasterize_gaussians_batch(*(args[:8] + (args[8][:1].expand(300, 4, 4), args[9][:1].expand(300, 4, 4)) + args[10:16] +
+                                      (args[16][:1].expand(300, 3),) + args[17:]))
