@@ -32,9 +32,9 @@ def test_arena_size_queries():
         b = lib.gsr_geom_bytes(P)
         assert b >= prev and b % 256 == 0
         prev = b
-    # SoA arena: 64-B splat line + 64-B gradient record + keys/ids/rect per Gaussian -> ~157 B/Gaussian + per-workgroup
-    # histograms and prefix-sum status words
-    assert 150 * 800_000 < lib.gsr_geom_bytes(800_000) < 165 * 800_000
+    # SoA arena: 64-B splat line + 64-B gradient record + depth keys/ids/tile count/clamp mask per Gaussian -> ~149 B/Gaussian
+    # + per-workgroup histograms and prefix-sum status words
+    assert 140 * 800_000 < lib.gsr_geom_bytes(800_000) < 160 * 800_000
     # binning: two key + two u32 id buffers (16 B/pair) + the backward pass's chunk-boundary state (4 KB per 1024
     # pairs = 4 B/pair); the reference needs 24 B/pair + CUB temp
     assert 20 * 11_500_000 <= lib.gsr_binning_bytes(11_500_000) < 21 * 11_500_000
