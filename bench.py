@@ -321,8 +321,11 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             kname = {"render_backward": "k_render_backward", "render_forward": "k_render_forward"}.get(dom, dom)
+            scale = VPC / float(pmc.get("views_per_launch", 1))      # the profile's launches covered that many views each
             traffic = pmc.get("bytes_per_launch", {}).get(kname)
             valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
+            traffic = None if traffic is None else int(traffic * scale)
+            valu = None if valu is None else valu * scale
         except (OSError, ValueError):
             traffic = None
         if dom is not None:
@@ -332,7 +335,7 @@ def main():
                         "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(avg_ms[dom], 4),
                         "views_per_launch": VPC}
             if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
-                rate = valu * VPC / (avg_ms[dom] * 1e-3)
+                rate = valu / (avg_ms[dom] * 1e-3)
                 roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
                                     "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
                                     "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json"}

@@ -1,10 +1,11 @@
 """Copy the judged artefacts of a scripts/profile_gpu.sh run from gpurun_out/prof_<tag>/ into profiles/ and rebuild
 profiles/pmc_traffic.json (HBM-side bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE passes).
-usage: python scripts/update_profiles.py [tag]"""
+usage: python scripts/update_profiles.py [tag [views_per_launch]]"""
 import csv, glob, json, os, shutil, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+views_per_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 12     # bench.py --views-per-call of the profiled command
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -29,6 +30,7 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for k in acc:
         raw[k][counter + "_KiB"] = acc[k] / max(len(launches[k]), 1)
 out = {
+    "views_per_launch": views_per_launch,
     "source": "profiles/%s_bench_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --streams 1)" % tag,
     "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; x2 is the gfx950 FETCH_SIZE half-count correction of "
                "MI355X_MICROARCH.md (calibrated there for wide coalesced reads; the render kernels' 16-B gathers are not "
