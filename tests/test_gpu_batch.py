@@ -210,3 +210,27 @@ def test_batch_edge_cases_vs_oracle(oracle, gpu_device):
     with pytest.raises(RuntimeError, match="view count"):
         N.rasterize_gaussians_batch(*(args[:8] + (args[8][:1].expand(300, 4, 4), args[9][:1].expand(300, 4, 4)) + args[10:16] +
                                       (args[16][:1].expand(300, 3),) + args[17:]))
+
+
+def test_batch_debug_and_prefiltered_trap(gpu_device):
+    """debug = True synchronises and checks after every launch of a batch (the reference's CHECK_CUDA); prefiltered = True with
+    a Gaussian behind some view's near plane raises with the reference's text instead of trapping the device."""
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(3, P=3000)
+    args = list(_batch_args(g, views, W, H, dev))
+    ok_counts, ok_color, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)
+    dbg = list(args)
+    dbg[18] = True
+    c2, col2, *_ = N.rasterize_gaussians_batch(*dbg, need_backward=False)
+    assert c2 == ok_counts and torch.equal(col2, ok_color)
+    pre = list(args)
+    pre[17] = True
+    c3, col3, *_ = N.rasterize_gaussians_batch(*pre, need_backward=False)          # nothing is culled: fine
+    assert c3 == ok_counts and torch.equal(col3, ok_color)
+    m = pre[1].clone()
+    m[7] = torch.tensor([0.0, 0.0, 50.0], device=dev)                                # far behind every camera looking at the origin
+    pre[1] = m
+    # the point lies behind the camera of at least one of the circle views
+    with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+        N.rasterize_gaussians_batch(*pre, need_backward=False)
