@@ -73,14 +73,12 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
         cnt = __float_as_uint(q3.z);
     }
     // ---- prefix sum: inside the wave, over the workgroup's waves, over the preceding workgroups ----
-    uint32_t inc = cnt;   // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: wave sums are carried in 64 bits below
-    uint64_t inc64 = cnt;
+    uint64_t inc64 = cnt;   // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: sums are carried in 64 bits
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc64, d, 64);
         if (lane >= (uint32_t)d) inc64 += n;
     }
-    (void)inc;
     if (lane == 63) s_wave[w] = inc64;
     __syncthreads();
     uint64_t wave_base = 0;

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization import rasterize_views as _rasterize_views_call
 from diff_gaussian_rasterization import _native
 
 from . import camera as _camera
@@ -43,8 +44,11 @@ def _finish(frames, batchsize, num_q, h, w, ss):
 
 
 def rasterize_views(means3D_list, opacity_list, scales_list, rotations_list, H_c2w, h, w, fov, bg, scale_factor,
-                    shs_list=None, colors_list=None, sh_degree=1, super_sample_rate=2, normalize_camera_normal=False):
-    """The reference's _rasterize: lists are per batch item, H_c2w is [b, q, 4, 4] (Camera.H_c2w)."""
+                    shs_list=None, colors_list=None, sh_degree=1, super_sample_rate=2, normalize_camera_normal=False,
+                    batch_views=False):
+    """The reference's _rasterize: lists are per batch item, H_c2w is [b, q, 4, 4] (Camera.H_c2w).  batch_views=True submits
+    the q views of a batch item in ONE rasterizer call (diff_gaussian_rasterization.rasterize_views; same images, gradients
+    summed over the views like autograd does for the loop) whenever the colours do not depend on the view."""
     batchsize, num_q = H_c2w.shape[0], H_c2w.shape[1]
     frames = []
     for i in range(batchsize):
@@ -54,6 +58,13 @@ def rasterize_views(means3D_list, opacity_list, scales_list, rotations_list, H_c
         radius = float(np.sqrt(3) / scale_factor * 6)   # simple_raw_render.py:248
         scales = scales_list[i] * radius
         colors_i = None if colors_list is None else colors_list[i]
+        if batch_views and not normalize_camera_normal:
+            sts = [settings_for_view(H_c2w[i, j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
+                   for j in range(num_q)]
+            imgs, _ = _rasterize_views_call(means3D, means2D, opacity_list[i], sts, shs=None if shs_list is None else shs_list[i],
+                                            colors_precomp=colors_i, scales=scales, rotations=rotations_list[i])
+            frames.extend(list(imgs))
+            continue
         for j in range(num_q):
             st = settings_for_view(H_c2w[i, j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
             if normalize_camera_normal:                 # simple_raw_render.py:264-268, incl. the sign-of-first-point quirk (Q11)

@@ -65,6 +65,11 @@ def test_render_passes_equals_four_literal_passes(gpu_device):
     for k in ("rgb", "xyz_w", "hitmap", "normal"):
         assert fused[k].shape == (1, 4, h, w, 3) == lit[k].shape
         assert torch.equal(fused[k], lit[k]), k
+    # the literal pattern with the views of a batch item submitted together
+    with torch.no_grad():
+        tog = rp.rasterize_views([means], [opac], [decoded_s], [rots], Hb, h, w, 45.0, bg, sf, shs_list=[shs], super_sample_rate=2,
+                                 batch_views=True)
+    assert torch.equal(tog, lit["rgb"])
     # hit map: 1 where the body covers the pixel (background 1 too here), strictly inside [0, 1]
     assert float(fused["hitmap"].min()) > 0.99 and float(fused["hitmap"].max()) <= 1.0 + 1e-6
 
