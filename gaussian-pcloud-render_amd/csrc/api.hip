@@ -108,12 +108,12 @@ struct ProfScope {
 // ---- per-thread pinned landing zone for the counter read-back ------------------------------------------
 constexpr int MAX_VIEWS = 256;
 struct HostLanding {
-    uint64_t* pinned = nullptr;   // [MAX_VIEWS][2]: num_rendered, trap flag
+    uint64_t* pinned = nullptr;   // [MAX_VIEWS][4]: num_rendered, trap flag, stall flag, -
     hipEvent_t ev = nullptr;
     int ensure()
     {
         if (pinned) return GSR_OK;
-        if (hipHostMalloc((void**)&pinned, MAX_VIEWS * 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc((void**)&pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
             pinned = nullptr;
             return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
@@ -238,8 +238,8 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     }
     // counters of every view -> pinned host memory; waited for only after the rest of the frame has been enqueued
     {
-        hipError_t e = V == 1 ? hipMemcpyAsync(t_land.pinned, B.g.counters, 16, hipMemcpyDeviceToHost, L.stream)
-                              : hipMemcpy2DAsync(t_land.pinned, 16, B.g.counters, B.g_stride, 16, (size_t)V, hipMemcpyDeviceToHost, L.stream);
+        hipError_t e = V == 1 ? hipMemcpyAsync(t_land.pinned, B.g.counters, 32, hipMemcpyDeviceToHost, L.stream)
+                              : hipMemcpy2DAsync(t_land.pinned, 32, B.g.counters, B.g_stride, 32, (size_t)V, hipMemcpyDeviceToHost, L.stream);
         if (e == hipSuccess) e = hipEventRecord(t_land.ev, L.stream);
         if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
     }
@@ -266,8 +266,10 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
     bool retry = false;
     for (int v = 0; v < V; v++) {
-        const uint64_t R = t_land.pinned[2 * v];
-        if (p->prefiltered && t_land.pinned[2 * v + 1])
+        const uint64_t R = t_land.pinned[4 * v];
+        if (t_land.pinned[4 * v + CNT_STALL])
+            return fail(GSR_ERR_HIP, "[gsr] pair emission: a workgroup's pair count never arrived (view %d)", v);
+        if (p->prefiltered && t_land.pinned[4 * v + CNT_TRAP])
             return fail(GSR_ERR_TRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
         // the reference keeps num_rendered in an int (CR/rasterizer_impl.cu:280); beyond that its arena sizes wrap
         if (R > 0x7FFFFFFFull)

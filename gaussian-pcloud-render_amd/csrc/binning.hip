@@ -92,7 +92,14 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     uint64_t part = 0;
     for (uint32_t b = threadIdx.x; b < blk; b += DUP_THREADS) {
         uint64_t v;
-        do { v = agent_load(&status[b]); } while (v == 0);
+        uint32_t spins = 0;
+        do {
+            v = agent_load(&status[b]);
+            if (v == 0 && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
+                at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
+                v = 1;
+            }
+        } while (v == 0);
         part += v - 1;
     }
 #pragma unroll

@@ -65,6 +65,8 @@ constexpr int GRAD_REC_WORDS = 16;
 // counters[] slots (geometry arena, per view)
 constexpr int CNT_NUM_RENDERED = 0;  // true number of (tile, Gaussian) pairs, even when it exceeds the arena capacity
 constexpr int CNT_TRAP = 1;          // prefiltered = 1 but a Gaussian was culled
+constexpr int CNT_STALL = 2;         // the pair emission gave up waiting for a preceding workgroup's count (never expected;
+                                     // cleared by k_preprocess, checked by the host: every spin in the library is bounded)
 
 // ---- arena views (device pointers carved out of the caller's opaque buffers) -------------------
 struct GeomView {

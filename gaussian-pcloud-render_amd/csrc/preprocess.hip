@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     {
         const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
         for (int vw = v_first; vw < v_last; vw++) {
+            if (gtid == 0) at_view(a.counters, a.g_stride, vw)[CNT_STALL] = 0;
             zero_region(a.g_zero + a.g_stride * vw, a.g_zero_bytes, gtid, nthr);
             zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
         }
