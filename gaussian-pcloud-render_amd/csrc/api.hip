@@ -444,6 +444,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     const int P = p->P, T = tile_count(p);
     const int64_t N = (int64_t)p->W * p->H;
     const GeomView g = geom_view(align256(const_cast<void*>(geom)), P);
+    if (binning && binning_bytes < 512) return fail(GSR_ERR_CAPACITY, "[gsr] query: binning arena too small");
     const int64_t cap = binning ? bin_capacity_from_bytes(((binning_bytes - 256)) / 256 * 256) : 0;
     if (binning && R > cap) return fail(GSR_ERR_CAPACITY, "[gsr] query: arena holds %lld pairs, R = %lld", (long long)cap, (long long)R);
     const BinView b = bin_view(align256(const_cast<void*>(binning)), cap > 0 ? cap : 1);
