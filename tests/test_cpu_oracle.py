@@ -193,3 +193,18 @@ def test_gradients_against_finite_differences(oracle):
             pm[key][idx] -= eps
             fd = (loss(pp) - loss(pm)) / (2 * eps)
             assert abs(fd - an[idx]) <= 0.05 * max(abs(fd), abs(an[idx])) + 0.02, (key, idx, fd, an[idx])
+
+
+@pytest.mark.parametrize("name", ["random_aniso", "sh_deg2", "sh_deg3", "cov3d_precomp", "scale_modifier", "capsule_circle"])
+def test_fp64_gaussian_backward_agrees_with_the_oracle(name, oracle):
+    """tests/fp64_backward.py (the float64 arbiter of the randomised sweep, written from the formulas, not from the
+    reference's expression list) against the float32 oracle on well-conditioned scenes."""
+    import util
+    from fp64_backward import gaussian_backward_fp64
+    s = util.build_scene(name)
+    f, g = oracle.forward_backward(s, util.seeded_dL(s))
+    t = gaussian_backward_fp64(s, f["radii"], f["clamped"], g["dL_dmean2D"], g["dL_dconic"], g["dL_dcolor"])
+    assert set(t) >= {"dL_dmean3D", "dL_dcov3D"}
+    for k, v in t.items():
+        a = g[k].astype(np.float64).reshape(v.shape)
+        assert np.abs(a - v).max() <= 5e-6 * np.abs(v).max() + 1e-12, k

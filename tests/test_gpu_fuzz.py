@@ -12,7 +12,8 @@ from util import run_product
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 128
+import os
+N_CASES = int(os.environ.get("GSR_FUZZ_CASES", "512"))
 
 
 def _ref():
@@ -81,19 +82,42 @@ def test_random_case_matches_reference_build(i, gpu_device):
         if bad_el == 0 and bad_row == 0:
             continue
         # Both sides sum thousands of fp32 terms in different (for the reference: unspecified, atomic) orders, and the
-        # per-Gaussian chain conic -> cov3D -> scale / rotation can amplify that rounding noise by 10^3 on an
-        # ill-conditioned splat (run-to-run variation of BOTH sides at the 1e-4 level has been observed on such cases).
-        # When they disagree beyond the bar, the plain-C oracle, which accumulates in double, arbitrates: the library
-        # must be about as close to it as the reference build is (factor 4 for the noise of a single run).
+        # per-Gaussian chain conic -> cov3D -> scale / rotation / mean can amplify that rounding noise by 10^3..10^5 on an
+        # ill-conditioned splat (a nearly singular conic).  The plain-C oracle is no arbiter there: it evaluates that chain
+        # in float32 with the reference's own expression order, so it shares the reference build's rounding.  The exact
+        # value comes from the float64 chain of tests/fp64_backward.py fed with the oracle's double-accumulated
+        # render-level sums; the library must be inside the usual bar against it, or no further from it than 4x the
+        # reference build's own distance, row by row.
         if oracle_grads is None:
             from oracle.oracle import Oracle
-            oracle_grads = Oracle().forward_backward(s, dL)[1]
-        o = oracle_grads[k].astype(np.float64).reshape(a.shape[0], -1)
+            from fp64_backward import gaussian_backward_fp64
+            of, og = Oracle().forward_backward(s, dL)   # noqa: F841 (of / og are used by the conditioning check below)
+            oracle_grads = dict(og)
+            oracle_grads.update(gaussian_backward_fp64(s, of["radii"], of["clamped"], og["dL_dmean2D"], og["dL_dconic"], og["dL_dcolor"]))
+        o = np.asarray(oracle_grads[k], np.float64).reshape(a.shape[0], -1)
         a2, b2 = a.astype(np.float64).reshape(a.shape[0], -1), b.astype(np.float64).reshape(a.shape[0], -1)
         rn = np.linalg.norm(o, axis=1)
         r_lib, r_build = np.linalg.norm(a2 - o, axis=1), np.linalg.norm(b2 - o, axis=1)
-        # per Gaussian row: inside the usual bar against the double-precision oracle, or no further from it than 4x the
-        # reference build's own distance for that row
         ok = r_lib <= np.maximum(util.ROW_REL * rn + util.ROW_ABS * rn.max(), 4 * r_build) + 1e-30
-        assert ok.all(), "case %d %s: %d rows; worst lib-oracle %.3g (ref-oracle %.3g there), lib-ref max %.3g, max|g| %.3g" % (
+        if not ok.all() and k in ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
+            # Still outside: is the row simply that ill-conditioned?  (a) The render-level sums every float32 implementation
+            # feeds into the chain carry ~1e-6 of relative rounding noise: push noise of that size through the float64 chain
+            # and see how far the exact result moves.  (b) The chain itself rounds: run the very same expressions in float32
+            # and see how far THAT lands from the float64 result.  A row passes if the library is within 6 sigma of (a) or
+            # within 4x the distance (b) -- i.e. as good as float32 arithmetic gets on that splat.
+            bad = np.nonzero(~ok)[0]
+            rng = np.random.default_rng(4242 + i)
+            base = gaussian_backward_fp64(s, of["radii"], of["clamped"], og["dL_dmean2D"], og["dL_dconic"], og["dL_dcolor"], rows=bad)[k]
+            dev = np.zeros(bad.size)
+            for _ in range(8):
+                noisy = [np.asarray(og[n], np.float64) * (1.0 + 1e-6 * rng.standard_normal(np.asarray(og[n]).shape))
+                         for n in ("dL_dmean2D", "dL_dconic", "dL_dcolor")]
+                out = gaussian_backward_fp64(s, of["radii"], of["clamped"], *noisy, rows=bad)[k]
+                dev += ((out - base).reshape(bad.size, -1) ** 2).sum(1)
+            sigma = np.sqrt(dev / 8)
+            f32 = gaussian_backward_fp64(s, of["radii"], of["clamped"], og["dL_dmean2D"], og["dL_dconic"], og["dL_dcolor"], rows=bad,
+                                         dtype=np.float32)[k].astype(np.float64)
+            r_f32 = np.sqrt(((f32 - base).reshape(bad.size, -1) ** 2).sum(1))
+            ok[bad] = r_lib[bad] <= np.maximum(6 * sigma, 4 * r_f32)
+        assert ok.all(), "case %d %s: %d rows; worst lib-exact %.3g (ref-exact %.3g there), lib-ref max %.3g, max|g| %.3g" % (
             i, k, int((~ok).sum()), r_lib[~ok].max(), r_build[~ok][np.argmax(r_lib[~ok])], d_ref, scale)
