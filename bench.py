@@ -333,7 +333,9 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(avg_ms[dom], 4),
-                        "views_per_launch": VPC}
+                        "views_per_launch": VPC,
+                        "traffic_source": "(2*FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 PMC passes of this "
+                                          "command (profiles/pmc_traffic.json, scripts/profile_gpu.sh); avg_ms is measured live"}
             if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
                 rate = valu / (avg_ms[dom] * 1e-3)
                 roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
