@@ -5,7 +5,7 @@
 Workload (BASELINE.json metric, configs[2]): synth-THuman-800K -- 800 000 synthetic Gaussians
 ("training" profile: opacity U(0.2,1), SH degree 1 in 13 rows) rendered at 1920x1080 from the reference's 12
 `circle` cameras, forward + backward through the public GaussianRasterizer API, loss = sum(img * G).
-A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered on
+A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered (one collective per submission) on
 rank 0 with RCCL (weak scaling).  All inputs are resident in HBM before the timed region.
 Frames are submitted --views-per-call (default 12, one turn of the circle) at a time through rasterize_views -- the C ABI's
 gsr_forward_batch / gsr_backward_batch: every kernel covers all views of the submission, nothing on the host waits for
@@ -158,7 +158,10 @@ def main():
     means3D, shs, opac = leafsets[0]["means3D"], leafsets[0]["shs"], leafsets[0]["opacities"]
     scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
-    gather_list = [torch.empty((3, H, W), device="cpu" if host_collectives else dev) for _ in range(world)] \
+    VPC = max(1, args.views_per_call)
+    # the frames of one submission travel in ONE collective (up to VPC x 24.9 MB per rank at 1080p): fewer, larger transfers
+    # for the point-to-point xGMI links than a gather per frame
+    gather_bufs = [torch.empty((VPC, 3, H, W), device="cpu" if host_collectives else dev) for _ in range(world)] \
         if (use_dist and rank == 0) else None
 
     do_gather = use_dist and not args.no_gather
@@ -176,8 +179,6 @@ def main():
         with torch.no_grad():
             img, _ = rasterizers[v](**L)
         return img
-
-    VPC = max(1, args.views_per_call)
 
     def render_many(i, n, tslot=0):
         """Global steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
@@ -197,13 +198,11 @@ def main():
                                       rotations=L["rotations"])
         return imgs
 
-    def gather(img):
-        dist.gather(img.cpu() if host_collectives else img, gather_list=gather_list, dst=0)
-
-    def step(i, tslot=0):
-        img = render(i, tslot)
-        if do_gather:
-            gather(img)
+    def gather(imgs):
+        """imgs [n,3,H,W], n <= VPC: this rank's frames of one submission -> rank 0."""
+        n = imgs.shape[0]
+        dist.gather(imgs.cpu() if host_collectives else imgs.contiguous(),
+                    gather_list=[b[:n] for b in gather_bufs] if rank == 0 else None, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -223,7 +222,7 @@ def main():
             i += n
         multiview.run_frames_pipelined(lambda ci, slot: render_many(ch[ci][0], ch[ci][1], slot), 0, len(ch),
                                        args.streams if streams is None else streams,
-                                       on_frame=(lambda ci, imgs: [gather(im) for im in imgs]) if do_gather else None, device=dev)
+                                       on_frame=(lambda ci, imgs: gather(imgs)) if do_gather else None, device=dev)
 
     # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
     # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing
