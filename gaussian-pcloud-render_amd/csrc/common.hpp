@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/gsr.h"
 
 namespace gsr {
@@ -44,7 +46,10 @@ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 template <typename T>
 __host__ __device__ __forceinline__ T* at_view(T* p, size_t stride_bytes, uint32_t view)
 {
-    return (T*)((uintptr_t)p + stride_bytes * view);
+    // pointer arithmetic, not integer arithmetic: the compiler keeps the kernel argument's global address space and emits
+    // global_load / global_store (SGPR base + 32-bit lane offset) instead of flat accesses with 64-bit lane addresses
+    using B = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+    return (T*)((B*)p + stride_bytes * view);
 }
 
 // Per-Gaussian packed splat record: what the render kernels gather per list entry.  Padded to one 64-B cache line, so a

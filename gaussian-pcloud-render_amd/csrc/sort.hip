@@ -171,36 +171,57 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t blk_base = (int64_t)blk * RS_TILE;
     const int64_t seg_base = blk_base + (int64_t)w * (RS_TILE / RS_WAVES);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     for (int i = lane; i < RADIX; i += 64) wave_cnt[w][i] = 0;
 
     uint32_t k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
+    const bool full = blk_base + RS_TILE <= n;   // all but the last block of a view: no bounds checks
+    {
+        const KeyT* kp = keys_in + seg_base + lane;
+        const uint32_t* vp = vals_in ? vals_in + seg_base + lane : nullptr;
+        if (full) {
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
-        const int64_t idx = seg_base + j * 64 + lane;
-        const bool ok = idx < n;
-        k[j] = ok ? (uint32_t)keys_in[idx] : 0xFFFFFFFFu;
-        v[j] = ok ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;
+            for (int j = 0; j < RS_ITEMS; j++) k[j] = (uint32_t)kp[j * 64];
+            if (vp) {
+#pragma unroll
+                for (int j = 0; j < RS_ITEMS; j++) v[j] = vp[j * 64];
+            } else {
+#pragma unroll
+                for (int j = 0; j < RS_ITEMS; j++) v[j] = (uint32_t)(seg_base + j * 64 + lane);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RS_ITEMS; j++) {
+                const int64_t idx = seg_base + j * 64 + lane;
+                const bool ok = idx < n;
+                k[j] = ok ? (uint32_t)kp[j * 64] : 0xFFFFFFFFu;
+                v[j] = ok ? (vp ? vp[j * 64] : (uint32_t)idx) : 0u;
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
-    // stable rank inside the wave's segment: order is (j, lane)
+    // stable rank inside the wave's segment: order is (j, lane).  peers = the lanes holding my digit: one ballot per digit
+    // bit, folded in with one three-input bit operation per half (peers & ~(ballot ^ my bit)); the count of peers below me
+    // comes from mbcnt.  This loop is most of the kernel's instructions -- the scatter is VALU-bound, not HBM-bound.
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
-        const int64_t idx = seg_base + j * 64 + lane;
-        const bool ok = idx < n;
+        const bool ok = full || seg_base + j * 64 + lane < n;
         const uint32_t d = (k[j] >> shift) & mask;
-        uint64_t peers = __ballot(ok);
+        const uint64_t okb = full ? ~0ull : __ballot(ok);
+        uint32_t plo = (uint32_t)okb, phi = (uint32_t)(okb >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
+            const uint32_t m = (uint32_t)((int32_t)(d << (31 - b)) >> 31);   // all ones where my bit b is set
+            const uint64_t bal = __ballot(m != 0u);
+            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);          // a & ~(b ^ c)
+            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
         }
         const uint32_t before = wave_cnt[w][d];
-        rank[j] = before + (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        rank[j] = before + below;
         __builtin_amdgcn_wave_barrier();
-        if (ok && (peers & lt_mask) == 0) wave_cnt[w][d] = before + (uint32_t)__popcll(peers);
+        if (ok && below == 0) wave_cnt[w][d] = before + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -224,8 +245,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
 
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
-        const int64_t idx = seg_base + j * 64 + lane;
-        if (idx < n) {
+        if (full || seg_base + j * 64 + lane < n) {
             const uint32_t d = (k[j] >> shift) & mask;
             const uint32_t pos = local_base[d] + wave_cnt[w][d] + rank[j];
             s_key[pos] = k[j];
