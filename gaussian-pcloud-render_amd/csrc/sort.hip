@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
         uint32_t plo = (uint32_t)okb, phi = (uint32_t)(okb >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const uint32_t m = (uint32_t)((int32_t)(d << (31 - b)) >> 31);   // all ones where my bit b is set
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int32_t)k[j], (uint32_t)(shift + b), 1u);   // all ones where my bit b is set
             const uint64_t bal = __ballot(m != 0u);
             plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, m, 0x90);          // a & ~(b ^ c)
             phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), m, 0x90);
