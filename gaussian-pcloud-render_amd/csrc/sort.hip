@@ -90,11 +90,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const uint32_t w = (threadIdx.x >> 6) * 4u + (threadIdx.x & 3u);
-    if (sizeof(KeyT) == 2 && base + RS_TILE <= n) {
-        // full block of 16-bit keys: two 16-B loads per thread instead of sixteen 2-B ones (counting is order-free)
-        const uint4* k4 = reinterpret_cast<const uint4*>(keys + base) + threadIdx.x * 2;
+    if (sizeof(KeyT) == 2 && RS_ITEMS % 8 == 0 && base + RS_TILE <= n) {
+        // full block of 16-bit keys: 16-B loads of eight keys instead of 2-B ones (counting is order-free)
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + base) + threadIdx.x * (RS_ITEMS / 8);
 #pragma unroll
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < RS_ITEMS / 8; v++) {
             const uint4 q = k4[v];
             const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
