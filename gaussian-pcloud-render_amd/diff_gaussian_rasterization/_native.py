@@ -246,7 +246,7 @@ def recolor(background, means3D, colors, sh, degree, campos, image_height, image
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     single = campos.numel() == 3
     V = 1 if single else campos.reshape(-1, 3).shape[0]
-    out_color = torch.zeros((V, 3, H, W), dtype=torch.float32, device=device)
+    out_color = (torch.empty if P != 0 else torch.zeros)((V, 3, H, W), dtype=torch.float32, device=device)   # every pixel is written
     if P != 0:
         with torch.cuda.device(device):
             e = torch.empty(0)

@@ -35,9 +35,23 @@ def settings_for_view(H_c2w, width_px, height_px, fov_deg, device, sh_degree=0, 
         sh_degree=sh_degree, campos=a["campos"].to(device), prefiltered=False, debug=False)
 
 
+def settings_for_views(H_c2w, width_px, height_px, fov_deg, device, sh_degree=0, bg=None, super_sample_rate=2):
+    """settings_for_view for q views (H_c2w [q,4,4]): the matrices of all views are computed in one go on the host and reach
+    the device in one copy; the per-view settings hold slices of it (same values bit for bit)."""
+    q = H_c2w.shape[0]
+    a = _camera.raster_settings_batch(H_c2w.detach().cpu().float(), width_px, height_px, fov_deg, super_sample_rate)
+    packed = torch.cat([a["viewmatrix"].reshape(q, 16), a["projmatrix"].reshape(q, 16), a["campos"]], dim=1).to(device)
+    bg = torch.zeros(3, device=device) if bg is None else bg.to(device)
+    return [GaussianRasterizationSettings(
+        image_height=a["image_height"], image_width=a["image_width"], tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=bg,
+        scale_modifier=1.0, viewmatrix=packed[j, :16].reshape(4, 4), projmatrix=packed[j, 16:32].reshape(4, 4),
+        sh_degree=sh_degree, campos=packed[j, 32:35], prefiltered=False, debug=False) for j in range(q)]
+
+
 def _finish(frames, batchsize, num_q, h, w, ss):
     """stack -> [b*q,3,h*ss,w*ss] -> bilinear down-filter -> (b, q, h, w, 3)   (simple_raw_render.py:279-288)"""
-    x = torch.stack(frames, dim=0).reshape(batchsize * num_q, 3, h * ss, w * ss)
+    x = frames if torch.is_tensor(frames) else torch.stack(frames, dim=0)     # a [b*q,3,H,W] tensor is taken as it is
+    x = x.reshape(batchsize * num_q, 3, h * ss, w * ss)
     if ss > 1:
         x = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
     return x.reshape(batchsize, num_q, 3, h, w).permute(0, 1, 3, 4, 2)
@@ -58,15 +72,14 @@ def rasterize_views(means3D_list, opacity_list, scales_list, rotations_list, H_c
         radius = float(np.sqrt(3) / scale_factor * 6)   # simple_raw_render.py:248
         scales = scales_list[i] * radius
         colors_i = None if colors_list is None else colors_list[i]
+        sts = settings_for_views(H_c2w[i], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
         if batch_views and not normalize_camera_normal:
-            sts = [settings_for_view(H_c2w[i, j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
-                   for j in range(num_q)]
             imgs, _ = _rasterize_views_call(means3D, means2D, opacity_list[i], sts, shs=None if shs_list is None else shs_list[i],
                                             colors_precomp=colors_i, scales=scales, rotations=rotations_list[i])
             frames.extend(list(imgs))
             continue
         for j in range(num_q):
-            st = settings_for_view(H_c2w[i, j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
+            st = sts[j]
             if normalize_camera_normal:                 # simple_raw_render.py:264-268, incl. the sign-of-first-point quirk (Q11)
                 cam_orig = H_c2w[i, j, :3, 3].to(device)
                 sgn = (torch.sum((means3D - cam_orig) * colors_i, -1, keepdim=True) > 0).float() * 2 - 1
@@ -92,28 +105,35 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
     radius = float(np.sqrt(3) / scale_factor * 6)
     sc = (scales * radius).contiguous()
     e = torch.empty(0)
-    sts = [settings_for_view(H_c2w[j], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
-           for j in range(num_q)]
-    st = sts[0]
-    H, W = st.image_height, st.image_width
-    view = torch.stack([s.viewmatrix.reshape(4, 4) for s in sts]).contiguous()
-    proj = torch.stack([s.projmatrix.reshape(4, 4) for s in sts]).contiguous()
-    cam = torch.stack([s.campos.reshape(3) for s in sts]).contiguous()
+    # the settings of all views in one go, one host -> device copy (get_rasterize_param_from_camera per view is 0.2 ms of host
+    # time each: more than the views' whole front end takes on the GPU)
+    H_cpu = H_c2w.detach().cpu().float()
+    a = _camera.raster_settings_batch(H_cpu, w, h, fov, super_sample_rate)
+    H, W = a["image_height"], a["image_width"]
+    packed = torch.cat([a["viewmatrix"].reshape(num_q, 16), a["projmatrix"].reshape(num_q, 16), a["campos"],
+                        H_cpu[:, :3, 3]], dim=1).to(device)
+    view, proj, cam = packed[:, :16].contiguous(), packed[:, 16:32].contiguous(), packed[:, 32:35].contiguous()
+    bg_d = torch.zeros(3, device=device) if bg is None else bg.to(device)
     counts, rgb, radii, geom, binning, img = _native.rasterize_gaussians_batch(
-        st.bg, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, st.tanfovx, st.tanfovy, H, W, shs, sh_degree, cam, False,
-        False, need_backward=False)
+        bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
+        False, False, need_backward=False)
 
     def again(colors):
-        return _native.recolor(st.bg, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
+        return _native.recolor(bg_d, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
 
     out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)), "normal": None}
     if normals is not None:
-        per_view = []
-        colors_n = normals
+        # simple_raw_render.py:264-268 flips the normals view by view with the sign found for the FIRST point (quirk Q11) and
+        # carries the flipped array into the next view: colours_j = c_j * normals with c_j = -c_(j-1) * sgn_j, sgn_j = +1 iff
+        # (p0 - cam_j) . (c_(j-1) n0) > 0.  Multiplying by +-1 is exact, so the scalars c_j follow from the q dot products of
+        # the first point alone; the q coloured arrays are then one broadcast multiply instead of q rounds of small kernels.
+        cam_orig = packed[:, 35:38]
+        dots = torch.sum((means3D[0:1] - cam_orig) * normals[0:1], -1).cpu()      # [q], the reference's expression for point 0
+        c, cs = 1.0, []
         for j in range(num_q):
-            cam_orig = H_c2w[j, :3, 3].to(device)
-            sgn = (torch.sum((means3D - cam_orig) * colors_n, -1, keepdim=True) > 0).float() * 2 - 1
-            colors_n = colors_n * (-1) * sgn[0]          # carried across views exactly like the reference's loop
-            per_view.append(colors_n)
-        out["normal"] = again(torch.stack(per_view, 0).contiguous())
-    return {k: (None if v is None else _finish(list(v), 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}
+            sgn = 1.0 if float(dots[j]) * c > 0 else -1.0
+            c = c * (-1.0) * sgn
+            cs.append(c)
+        per_view = normals.unsqueeze(0) * torch.tensor(cs, device=device, dtype=normals.dtype).reshape(num_q, 1, 1)
+        out["normal"] = again(per_view.contiguous())
+    return {k: (None if v is None else _finish(v, 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}

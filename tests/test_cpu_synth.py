@@ -29,3 +29,16 @@ def test_gaussian_parameters_follow_the_reference_conventions():
     assert abs(np.linalg.norm(g["rotations"], axis=1).mean() - 1) < 0.05 and not np.allclose(np.linalg.norm(g["rotations"], axis=1), 1)
     gi = synth.make_gaussians(c, profile="inference", seed=1)
     assert (gi["opacities"] == 1).all() and not gi["shs"][:, 1:].any()
+
+
+def test_batched_view_settings_are_bit_identical_to_per_view():
+    import torch
+    from pcrender import camera
+    Hs = camera.circle_path(12, 0, 3, [90, 0])
+    b = camera.raster_settings_batch(Hs, 960, 540, 45.0, 2)
+    assert (b["image_height"], b["image_width"]) == (1080, 1920)
+    for j in range(12):
+        a = camera.raster_settings_arrays(Hs[j], 960, 540, 45.0, 2)
+        assert a["tanfovx"] == b["tanfovx"] and a["tanfovy"] == b["tanfovy"]
+        for k in ("viewmatrix", "projmatrix", "campos"):
+            assert torch.equal(a[k], b[k][j]), (k, j)
