@@ -196,7 +196,8 @@ static int memset_views(hipStream_t s, void* base, size_t stride, size_t bytes, 
 // The whole forward for a batch.  mode 0: everything; 1 (resume): from the pair emission on, after a GSR_RETRY or a
 // count-only call; 2 (count only): geometry + pair counting, no binning arena.
 static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
-                        size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int mode, hipStream_t stream)
+                        size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int mode, hipStream_t stream,
+                        const ExtraChannels* X = nullptr)
 {
     if (int e = check_params(p, V)) return e;
     if (!num_rendered) return fail(GSR_ERR_INVALID, "[gsr] num_rendered is NULL");
@@ -259,7 +260,7 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         }
         {
             ProfScope ps("render_forward", L.stream);
-            if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0)) return e;
+            if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0, X)) return e;
         }
     }
     if (hipEventSynchronize(t_land.ev) != hipSuccess)
@@ -301,6 +302,18 @@ int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes,
 {
     return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
                         resume ? 1 : 0, (hipStream_t)stream);
+}
+
+int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
+                               void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume,
+                               int nx, const float* extra, const float* extra_view_scale, const float* bg_extra, float* out_extra,
+                               gsr_stream_t stream)
+{
+    if (nx != 4 && nx != 8) return fail(GSR_ERR_INVALID, "[gsr] extra channels come in 4 or 8 (got %d): pad with zeros", nx);
+    if (!extra || !bg_extra || !out_extra) return fail(GSR_ERR_INVALID, "[gsr] an extra-channel pointer is NULL");
+    const ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra};
+    return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
+                        resume ? 1 : 0, (hipStream_t)stream, &X);
 }
 
 int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void* image, size_t image_bytes, int* radii,

@@ -267,8 +267,16 @@ int launch_tile_order(const Launch& L, const Batch& B, int T);
 int launch_bwd_items(const Launch& L, const Batch& B, int T);
 // render_fwd.hip / render_bwd.hip
 // point_list: view 0's sorted ids (binning arena); with_ckpt: record the chunk-boundary state for the backward pass
+// Extra channels composited by the forward render with the alphas of the colour pass (4 or 8 per call).
+struct ExtraChannels {
+    int nx;                   // 4 or 8
+    const float* values;      // [P][nx]
+    const float* view_scale;  // [V][nx] or NULL
+    const float* bg;          // [nx]
+    float* out;               // [V][nx][H][W]
+};
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
-                          bool with_ckpt);
+                          bool with_ckpt, const ExtraChannels* X = nullptr);
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix);
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
 #ifdef GSR_STATS

@@ -43,6 +43,11 @@ struct RenderArgs {
     float* accum;   // [3N] accumulated colour without background (written with ckpt, for quadrants that crossed a chunk boundary)
     uint32_t V;                              // views in the batch
     size_t g_stride, b_stride, iv_stride;    // bytes between consecutive views' arenas
+    // extra channels (k_render_forward<NX>, NX > 0): composited with the same alphas as the colour
+    const float* extra;        // [P][NX] per-Gaussian values, shared by the views
+    const float* extra_scale;  // [V][NX] per-view factors applied to them (NULL: 1), e.g. the +-1 of view-dependent normals
+    const float* bg_extra;     // [NX]
+    float* out_extra;          // [V][NX][H][W]
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -66,6 +71,11 @@ __device__ __forceinline__ void prefetch4f(float& dst, const void* p)
 __device__ __forceinline__ void retire_prefetch(f32x4& a, f32x4& b, float& c, uint32_t& d)
 {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+__device__ __forceinline__ void retire_prefetch_x(f32x4& a, f32x4& b, float& c, uint32_t& d, f32x4& e, f32x4& f)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)::"memory");
 }
 
 // exp(x) for the compositing loop.  Instruction-for-instruction the core of the ocml expf that `exp(power)` of the
@@ -110,8 +120,10 @@ __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x)
 // loads (s_load through the scalar cache) have the right cost but ~1 us latency, which the serial walk of the
 // longest lists cannot hide.  A wave owns its 2.5 KB of LDS: no barrier anywhere (DS operations of one wave execute
 // in order).
+// With NX extra channels a pair record grows by 2 NX words: for every two channels (k, k+1) the quad
+// (k of entry 0, k+1 of entry 0, k of entry 1, k+1 of entry 1), the layout of `rg`.
 constexpr int PAIR_WORDS = 20;
-
+template <int NX>
 struct PairRec {
     f32x4 xy;   // x0 x1 y0 y1
     f32x4 ab;   // A0 A1 B0 B1
@@ -119,22 +131,29 @@ struct PairRec {
     f32x4 rg;   // r0 g0 r1 g1
     f32x2 b;    // b0 b1
     uint2 pos;  // 1-based list positions of the two entries
+    f32x4 ex[NX > 0 ? NX / 2 : 1];
 };
-__device__ __forceinline__ PairRec read_pair(const float* lds, int pair)
+template <int NX>
+__device__ __forceinline__ PairRec<NX> read_pair(const float* lds, int pair)
 {
-    const float* p = lds + pair * PAIR_WORDS;
-    PairRec r;
+    const float* p = lds + pair * (PAIR_WORDS + 2 * NX);
+    PairRec<NX> r;
     r.xy = *(const f32x4*)(p + 0);
     r.ab = *(const f32x4*)(p + 4);
     r.co = *(const f32x4*)(p + 8);
     r.rg = *(const f32x4*)(p + 12);
     r.b = *(const f32x2*)(p + 16);
     r.pos = *(const uint2*)(p + 18);
+#pragma unroll
+    for (int j = 0; j < NX / 2; j++) r.ex[j] = *(const f32x4*)(p + PAIR_WORDS + 4 * j);
     return r;
 }
 
+template <int NX>
 __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 {
+    static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
+    constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
     // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
     // are fetched into that L2 once instead of four times.
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     // keep entries that can reach one of those
     float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 7.f;
 
-    __shared__ __attribute__((aligned(16))) float stage[33 * PAIR_WORDS];   // 32 pairs + one that may be read, never used
+    __shared__ __attribute__((aligned(16))) float stage[33 * PW];   // 32 pairs + one that may be read, never used
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -175,6 +194,15 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     float T = 1.0f;
     f32x2 C01 = {0.f, 0.f};
     float C2 = 0.f;
+    f32x2 CX[NX > 0 ? NX / 2 : 1];   // extra channels, two per register pair
+#pragma unroll
+    for (int j = 0; j < (NX > 0 ? NX / 2 : 1); j++) CX[j] = f32x2{0.f, 0.f};
+    f32x4 xs0 = {1.f, 1.f, 1.f, 1.f}, xs1 = {1.f, 1.f, 1.f, 1.f};   // this view's factors for the extra channels
+    if (NX > 0 && a.extra_scale != nullptr) {
+        const float* sc = a.extra_scale + (size_t)view * NX;
+        xs0 = f32x4{sc[0], sc[1], sc[2], sc[3]};
+        if (NX > 4) xs1 = f32x4{sc[4], sc[5], sc[6], sc[7]};
+    }
     uint32_t last_contributor = 0;
     uint32_t stop_at = 0;  // 1-based index of the entry that terminated this pixel
     bool crossed = false;  // this quadrant walked past a BWD_CHUNK boundary (wave-uniform)
@@ -192,6 +220,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         // Lanes past the end of the list read entry total-1 again (always a valid address) and are masked by `valid`.
         const int last = total - 1;
         f32x4 c0, c1, n0, n1;
+        f32x4 cx0 = {0.f, 0.f, 0.f, 0.f}, cx1 = cx0, nx0 = cx0, nx1 = cx0;   // extra channels of the entry
         float c2b, n2b;  // blue
         uint32_t id_cur, id_nxt, id_nn;
         {
@@ -204,7 +233,14 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
             prefetch16(c0, &sp->q0);
             prefetch16(c1, &sp->q1);
             prefetch4f(c2b, &sp->q2);
-            retire_prefetch(c0, c1, c2b, id_nxt);
+            if (NX > 0) {
+                const float* xp = a.extra + (size_t)id_cur * NX;
+                prefetch16(cx0, xp);
+                if (NX > 4) prefetch16(cx1, xp + 4);
+                retire_prefetch_x(c0, c1, c2b, id_nxt, cx0, cx1);
+            } else {
+                retire_prefetch(c0, c1, c2b, id_nxt);
+            }
         }
         for (int base = 0; base < total; base += 64) {
             {
@@ -212,6 +248,11 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 prefetch16(n0, &sp->q0);
                 prefetch16(n1, &sp->q1);
                 prefetch4f(n2b, &sp->q2);
+                if (NX > 0) {
+                    const float* xp = a.extra + (size_t)id_nxt * NX;
+                    prefetch16(nx0, xp);
+                    if (NX > 4) prefetch16(nx1, xp + 4);
+                }
                 const int i2 = base + 128 + (int)lane;
                 prefetch4(id_nn, plist + (i2 < total ? i2 : last));
             }
@@ -233,26 +274,48 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 const uint32_t nsurv = (uint32_t)__popcll(mask);
                 if (touch) {
-                    float* p = stage + (slot >> 1) * PAIR_WORDS + (slot & 1u);
+                    float* p = stage + (slot >> 1) * PW + (slot & 1u);
                     p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
-                    float* pc = stage + (slot >> 1) * PAIR_WORDS + 12 + 2 * (slot & 1u);
+                    float* pc = stage + (slot >> 1) * PW + 12 + 2 * (slot & 1u);
                     pc[0] = c1.z; pc[1] = c1.w;
                     p[16] = c2b;
                     const uint32_t my_pos = (uint32_t)(base + (int)lane + 1);   // 1-based list position
                     uint32_t* pp = (uint32_t*)p;
                     pp[18] = my_pos;
+                    f32x4 e0 = cx0, e1 = cx1;
+                    if (NX > 0) {
+                        e0 *= xs0;            // times +-1 (or any per-view factor): one multiply per staged value, not per pixel
+                        if (NX > 4) e1 *= xs1;
+                        float* px_ = stage + (slot >> 1) * PW + PAIR_WORDS + 2 * (slot & 1u);
+                        *(f32x2*)(px_ + 0) = f32x2{e0.x, e0.y};
+                        *(f32x2*)(px_ + 4) = f32x2{e0.z, e0.w};
+                        if (NX > 4) {
+                            *(f32x2*)(px_ + 8) = f32x2{e1.x, e1.y};
+                            *(f32x2*)(px_ + 12) = f32x2{e1.z, e1.w};
+                        }
+                    }
                     if (slot + 1 == nsurv && (slot & 1u) == 0) {
                         // odd count: the missing partner is a copy with opacity 0 -> alpha 0 -> the 1/255 test drops it
                         p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
                         pc[2] = c1.z; pc[3] = c1.w;
                         p[17] = c2b;
                         pp[19] = my_pos;
+                        if (NX > 0) {
+                            float* px_ = stage + (slot >> 1) * PW + PAIR_WORDS + 2;
+                            *(f32x2*)(px_ + 0) = f32x2{e0.x, e0.y};
+                            *(f32x2*)(px_ + 4) = f32x2{e0.z, e0.w};
+                            if (NX > 4) {
+                                *(f32x2*)(px_ + 8) = f32x2{e1.x, e1.y};
+                                *(f32x2*)(px_ + 12) = f32x2{e1.z, e1.w};
+                            }
+                        }
                     }
                 }
                 // Pair p+1 is read from LDS while pair p is evaluated.  The loop body is written out twice with the two
                 // register sets swapped, so no register moves are needed to rotate them.
-                auto eval_pair = [&](const PairRec& r) {
-                    __builtin_amdgcn_s_waitcnt(0xC57F);   // lgkmcnt(5): this pair has landed (DS returns in order); the five reads of the next pair stay in flight
+                auto eval_pair = [&](const PairRec<NX>& r) {
+                    // this pair has landed (DS returns in order); the 5 + NX / 2 reads of the next pair stay in flight
+                    __builtin_amdgcn_s_waitcnt(NX == 0 ? 0xC57F : NX == 4 ? 0xC77F : 0xC97F);   // lgkmcnt(5 / 7 / 9)
                     // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
                     // share packed fp32 instructions (v_pk_*_f32).
                     const uint32_t eidx0 = r.pos.x, eidx1 = r.pos.y;
@@ -277,6 +340,11 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         C2 += r.b.x * ae0 * T;
                         C01 += rg1 * ae1 * T1;
                         C2 += r.b.y * ae1 * T1;
+#pragma unroll
+                        for (int j = 0; j < NX / 2; j++) {
+                            CX[j] += f32x2{r.ex[j].x, r.ex[j].y} * ae0 * T;
+                            CX[j] += f32x2{r.ex[j].z, r.ex[j].w} * ae1 * T1;
+                        }
                         last_contributor = cnt0 ? eidx0 : last_contributor;
                         last_contributor = cnt1 ? eidx1 : last_contributor;
                         T = T2;
@@ -295,6 +363,11 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         C2 += r.b.x * be0 * T;
                         C01 += rg1 * be1 * U1;
                         C2 += r.b.y * be1 * U1;
+#pragma unroll
+                        for (int j = 0; j < NX / 2; j++) {
+                            CX[j] += f32x2{r.ex[j].x, r.ex[j].y} * be0 * T;
+                            CX[j] += f32x2{r.ex[j].z, r.ex[j].w} * be1 * U1;
+                        }
                         last_contributor = b0 ? eidx0 : last_contributor;
                         last_contributor = b1 ? eidx1 : last_contributor;
                         T = U2;
@@ -313,21 +386,23 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 // and the loop ends on the pair count alone: when every pixel is done the count is set to 0.
                 int npairs = (int)((nsurv + 1u) >> 1);
                 int pair = 0;
-                PairRec ra = read_pair(stage, 0), rb;
+                PairRec<NX> ra = read_pair<NX>(stage, 0), rb;
                 for (;;) {
-                    rb = read_pair(stage, pair + 1);
+                    rb = read_pair<NX>(stage, pair + 1);
                     eval_pair(ra);
                     if (all_done) npairs = 0;
                     if (++pair >= npairs) break;
-                    ra = read_pair(stage, pair + 1);
+                    ra = read_pair<NX>(stage, pair + 1);
                     eval_pair(rb);
                     if (all_done) npairs = 0;
                     if (++pair >= npairs) break;
                 }
             }
-            retire_prefetch(n0, n1, n2b, id_nn);
+            if (NX > 0) retire_prefetch_x(n0, n1, n2b, id_nn, nx0, nx1);
+            else retire_prefetch(n0, n1, n2b, id_nn);
             if (all_done) break;
             c0 = n0; c1 = n1; c2b = n2b;
+            if (NX > 0) { cx0 = nx0; cx1 = nx1; }
             id_cur = id_nxt;
             id_nxt = id_nn;
         }
@@ -352,6 +427,14 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         a.out_color[pix] = C01.x + T * a.bg[0];
         a.out_color[N + pix] = C01.y + T * a.bg[1];
         a.out_color[2 * N + pix] = C2 + T * a.bg[2];
+        if (NX > 0) {
+            float* ox = a.out_extra + (size_t)view * NX * N + pix;
+#pragma unroll
+            for (int j = 0; j < NX / 2; j++) {
+                ox[(size_t)(2 * j) * N] = CX[j].x + T * a.bg_extra[2 * j];
+                ox[(size_t)(2 * j + 1) * N] = CX[j].y + T * a.bg_extra[2 * j + 1];
+            }
+        }
         if (crossed) {   // only a backward slice that starts at a recorded boundary reads the final accumulated colour
             a.accum[pix] = C01.x;
             a.accum[N + pix] = C01.y;
@@ -361,7 +444,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 }
 
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
-                          bool with_ckpt)
+                          bool with_ckpt, const ExtraChannels* X)
 {
     RenderArgs a;
     a.ranges = B.iv.ranges;
@@ -383,7 +466,15 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     const int T = a.gridx * gridy;
     a.num_tiles = T;
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
-    hipLaunchKernelGGL(k_render_forward, dim3((unsigned)div_up(T, 8) * 32u * (unsigned)B.V), dim3(64), 0, L.stream, a);
+    a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr;
+    const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);
+    if (X != nullptr && X->nx > 0) {
+        a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out;
+        if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
+        else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
+    } else {
+        hipLaunchKernelGGL(k_render_forward<0>, grid, dim3(64), 0, L.stream, a);
+    }
     return check_launch(L, "render_forward");
 }
 

@@ -32,7 +32,7 @@ class GsrParams(C.Structure):
 # every symbol include/gsr.h declares (tests check the library exports all of them)
 SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
-           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor")
+           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels")
 
 GSR_RETRY = 1
 
@@ -55,6 +55,9 @@ def _load():
     lib.gsr_forward_batch.restype = C.c_int
     lib.gsr_forward_batch.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
                                       C.POINTER(C.c_int64), C.c_int, _fp]
+    lib.gsr_forward_batch_channels.restype = C.c_int
+    lib.gsr_forward_batch_channels.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
+                                               _fp, _fp, C.POINTER(C.c_int64), C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]
     lib.gsr_forward_stage1.restype = C.c_int
     lib.gsr_forward_stage1.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp,
                                        C.POINTER(C.c_int64), _fp]
@@ -163,10 +166,12 @@ def reset_capacity_hints():
 
 def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                              camposs, prefiltered, debug, need_backward=True, capacity=None):
+                              camposs, prefiltered, debug, need_backward=True, capacity=None, extra=None):
     """V views of one cloud in one submission (C ABI gsr_forward_batch): viewmatrices / projmatrices [V,4,4] (transposed like
     the reference's settings), camposs [V,3].  Returns (num_rendered list[V], out_color [V,3,H,W], radii [V,P],
-    geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity."""
+    geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity.
+    extra = (values [P,nx], view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the render also composites those channels
+    with the colour's alphas (gsr_forward_batch_channels) and the result gains a 7th element, out_extra [V,nx,H,W]."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = means3D.device
@@ -179,10 +184,23 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         raise RuntimeError("viewmatrices, projmatrices and camposs must describe the same number of views (>= 1)")
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     byte = dict(dtype=torch.uint8, device=device)
+    nx = 0
+    if extra is not None:
+        xv, xs, xb = extra
+        nx = int(xv.shape[1]) if xv.dim() == 2 else -1
+        if nx not in (4, 8) or xv.shape[0] != P:
+            raise RuntimeError("extra channels must have shape (num_points, 4) or (num_points, 8)")
+        xv = _f32c(xv, device, "extra")
+        xb = _f32c(xb.reshape(-1), device, "bg_extra")
+        if xb.numel() != nx or (xs is not None and tuple(xs.shape) != (V, nx)):
+            raise RuntimeError("bg_extra must have nx entries and view_scale shape (V, nx)")
+        xs = None if xs is None else _f32c(xs, device, "extra_view_scale")
     if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
         e = torch.empty((0,), **byte)
-        return ([0] * V, torch.zeros((V, 3, H, W), dtype=torch.float32, device=device),
-                torch.zeros((V, 0), dtype=torch.int32, device=device), e, e.clone(), e.clone())
+        r0 = ([0] * V, torch.zeros((V, 3, H, W), dtype=torch.float32, device=device),
+              torch.zeros((V, 0), dtype=torch.int32, device=device), e, e.clone(), e.clone())
+        return r0 if extra is None else r0 + (torch.zeros((V, nx, H, W), dtype=torch.float32, device=device),)
+    out_extra = torch.empty((V, nx, H, W), dtype=torch.float32, device=device) if nx else None
     # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
     out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((V, P), dtype=torch.int32, device=device)
@@ -198,7 +216,7 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         if capacity is None:
             hint = _CAP_HINT.get(key)
             capacity = None if hint is None else int(hint * CAP_SLACK) + 4096
-        if capacity is None and V == 1:
+        if capacity is None and V == 1 and not nx:
             # first frame of this configuration: count, then bind (one host round trip, like the reference)
             _check(lib.gsr_forward_stage1(C.byref(p), geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
                                           radii.data_ptr(), counts, stream))
@@ -208,20 +226,28 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         else:
             if capacity is None:
                 capacity = 16 * P      # first batch of this configuration: a guess, corrected by the retry below
+            def submit(binning, resume):
+                if nx:
+                    return lib.gsr_forward_batch_channels(
+                        C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(), binning.data_ptr(),
+                        binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, resume, nx, xv.data_ptr(),
+                        None if xs is None else xs.data_ptr(), xb.data_ptr(), out_extra.data_ptr(), stream)
+                return lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
+                                             binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts,
+                                             resume, stream)
+
             binning = torch.empty((V * lib.gsr_binning_bytes(int(capacity)),), **byte)
-            rc = lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
-                                       binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, 0,
-                                       stream)
+            rc = submit(binning, 0)
             if rc == GSR_RETRY:
                 need = int(max(counts) * CAP_SLACK) + 4096
                 binning = torch.empty((V * lib.gsr_binning_bytes(need),), **byte)
-                rc = lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
-                                           binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts,
-                                           1, stream)
+                rc = submit(binning, 1)
             _check(rc)
     del keep
     counts = [int(c) for c in counts]
     _note_counts(key, counts)
+    if nx:
+        return counts, out_color, radii, geom, binning, img, out_extra
     return counts, out_color, radii, geom, binning, img
 
 

@@ -97,9 +97,11 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
     """The four passes of PCML_Render.render for ONE cloud and q views (H_c2w [q,4,4]); returns a dict of
     (1, q, h, w, 3) tensors: 'rgb', 'xyz_w', 'hitmap' and 'normal' (None without normals).
 
-    All q views go through the pipeline front end in ONE submission (gsr_forward_batch, with the SH colours); xyz, ones and
-    the normals are re-rendered on the same sorted lists, again all views per call (the normals with per-view colours: the
-    reference flips their sign view by view).  Inference only (no autograd graph), like the reference's use."""
+    All q views go through the pipeline in ONE submission, and the four passes in ONE render: world xyz, the hit map and the
+    normals are extra channels of the colour render (gsr_forward_batch_channels; the normals with a per-view sign: the reference
+    flips them view by view).  With a background whose three values differ the hit map's channels differ too, and the passes
+    are re-rendered one by one on the sorted lists instead (gsr_forward_recolor).  Inference only (no autograd graph), like
+    the reference's use."""
     device = means3D.device
     num_q = H_c2w.shape[0]
     radius = float(np.sqrt(3) / scale_factor * 6)
@@ -114,19 +116,12 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
                         H_cpu[:, :3, 3]], dim=1).to(device)
     view, proj, cam = packed[:, :16].contiguous(), packed[:, 16:32].contiguous(), packed[:, 32:35].contiguous()
     bg_d = torch.zeros(3, device=device) if bg is None else bg.to(device)
-    counts, rgb, radii, geom, binning, img = _native.rasterize_gaussians_batch(
-        bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
-        False, False, need_backward=False)
-
-    def again(colors):
-        return _native.recolor(bg_d, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
-
-    out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)), "normal": None}
+    cs = None
     if normals is not None:
         # simple_raw_render.py:264-268 flips the normals view by view with the sign found for the FIRST point (quirk Q11) and
         # carries the flipped array into the next view: colours_j = c_j * normals with c_j = -c_(j-1) * sgn_j, sgn_j = +1 iff
         # (p0 - cam_j) . (c_(j-1) n0) > 0.  Multiplying by +-1 is exact, so the scalars c_j follow from the q dot products of
-        # the first point alone; the q coloured arrays are then one broadcast multiply instead of q rounds of small kernels.
+        # the first point alone.
         cam_orig = packed[:, 35:38]
         dots = torch.sum((means3D[0:1] - cam_orig) * normals[0:1], -1).cpu()      # [q], the reference's expression for point 0
         c, cs = 1.0, []
@@ -134,6 +129,32 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
             sgn = 1.0 if float(dots[j]) * c > 0 else -1.0
             c = c * (-1.0) * sgn
             cs.append(c)
-        per_view = normals.unsqueeze(0) * torch.tensor(cs, device=device, dtype=normals.dtype).reshape(num_q, 1, 1)
-        out["normal"] = again(per_view.contiguous())
+    bg_cpu = bg if (bg is not None and bg.device.type == "cpu") else bg_d.cpu()
+    if float(bg_cpu[0]) == float(bg_cpu[1]) == float(bg_cpu[2]):
+        # ONE render for the four passes: world xyz, the hit map's single channel and the normals ride along as extra channels
+        # of the colour render (gsr_forward_batch_channels) -- same alphas, same stopping decisions, the same sums term for term
+        P = means3D.shape[0]
+        one = torch.ones((P, 1), dtype=torch.float32, device=device)
+        nrm = normals if normals is not None else torch.zeros_like(means3D)
+        extra = torch.cat([means3D, one, nrm, torch.zeros_like(one)], dim=1).contiguous()                   # [P, 8]
+        scale = torch.ones((num_q, 8), dtype=torch.float32)
+        if cs is not None:
+            scale[:, 4:7] = torch.tensor(cs, dtype=torch.float32).reshape(num_q, 1)
+        counts, rgb, radii, geom, binning, img, ex = _native.rasterize_gaussians_batch(
+            bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
+            False, False, need_backward=False, extra=(extra, scale.to(device), bg_d[0:1].expand(8)))
+        out = {"rgb": rgb, "xyz_w": ex[:, 0:3], "hitmap": ex[:, 3:4].expand(num_q, 3, H, W),
+               "normal": None if normals is None else ex[:, 4:7]}
+    else:
+        counts, rgb, radii, geom, binning, img = _native.rasterize_gaussians_batch(
+            bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
+            False, False, need_backward=False)
+
+        def again(colors):
+            return _native.recolor(bg_d, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
+
+        out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)), "normal": None}
+        if normals is not None:
+            per_view = normals.unsqueeze(0) * torch.tensor(cs, device=device, dtype=normals.dtype).reshape(num_q, 1, 1)
+            out["normal"] = again(per_view.contiguous())
     return {k: (None if v is None else _finish(v, 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}

@@ -234,3 +234,54 @@ def test_batch_debug_and_prefiltered_trap(gpu_device):
     # the point lies behind the camera of at least one of the circle views
     with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
         N.rasterize_gaussians_batch(*pre, need_backward=False)
+
+
+@pytest.mark.parametrize("nx,V,need_backward", [(8, 3, False), (4, 1, False), (8, 2, True)])
+def test_extra_channels_equal_separate_colour_passes(gpu_device, nx, V, need_backward):
+    """gsr_forward_batch_channels: every extra channel is bit-for-bit what a full call with that channel as colors_precomp
+    renders (same alphas, transmittances and stops), the colour output and the bookkeeping are those of the plain call."""
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(V)
+    args = _batch_args(g, views, W, H, dev, bg=(0.25, 0.25, 0.25))
+    P = g["means3D"].shape[0]
+    rng = np.random.default_rng(31)
+    extra = _t(rng.normal(0, 1, (P, nx)).astype(np.float32), dev)
+    scale = _t(rng.choice([-1.0, 1.0, 0.5], (V, nx)).astype(np.float32), dev)
+    bgx = _t(rng.uniform(0, 1, nx).astype(np.float32), dev)
+    N.reset_capacity_hints()       # first call with a guessed capacity: covers the retry path of the channels entry point too
+    r = N.rasterize_gaussians_batch(*args, need_backward=need_backward, extra=(extra, scale, bgx))
+    counts, color, radii, geom, binning, img, out_x = r
+    assert out_x.shape == (V, nx, H, W)
+    c0, color0, radii0, geom0, binning0, img0 = N.rasterize_gaussians_batch(*args, need_backward=need_backward)
+    assert counts == c0 and torch.equal(color, color0) and torch.equal(radii, radii0)
+    for name in ("FINAL_T", "N_CONTRIB"):
+        for v in range(V):
+            assert torch.equal(N.query(name, P, W, H, counts[v], geom, binning, img, view=v, n_views=V),
+                               N.query(name, P, W, H, c0[v], geom0, binning0, img0, view=v, n_views=V))
+    e = torch.empty(0)
+    for k0 in range(0, nx, 3):
+        ks = [min(k0 + i, nx - 1) for i in range(3)]
+        for v in range(V):
+            cols = (extra[:, ks] * scale[v, ks]).contiguous()
+            a = list(args)
+            a[0] = bgx[ks].contiguous()
+            a[2], a[14] = cols, e                           # colors_precomp instead of SHs
+            a[8], a[9], a[16] = args[8][v], args[9][v], args[16][v]
+            _, ref, _, _, _, _ = N.rasterize_gaussians(*a, need_backward=False)
+            assert torch.equal(out_x[v, ks], ref), (k0, v)
+
+
+def test_extra_channels_argument_checks(gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    g, views, W, H = _views_scene(1, P=500)
+    args = _batch_args(g, views, W, H, dev)
+    P = g["means3D"].shape[0]
+    with pytest.raises(RuntimeError, match="extra channels"):
+        N.rasterize_gaussians_batch(*args, need_backward=False, extra=(torch.zeros(P, 5, device=dev), None, torch.zeros(5, device=dev)))
+    with pytest.raises(RuntimeError, match="bg_extra"):
+        N.rasterize_gaussians_batch(*args, need_backward=False, extra=(torch.zeros(P, 4, device=dev), None, torch.zeros(3, device=dev)))
+    with pytest.raises(RuntimeError, match="view_scale"):
+        N.rasterize_gaussians_batch(*args, need_backward=False,
+                                    extra=(torch.zeros(P, 4, device=dev), torch.zeros(2, 4, device=dev), torch.zeros(4, device=dev)))
