@@ -319,7 +319,7 @@ def main():
         try:  # HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KiB -> B)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            kname = {"render_backward": "k_render_backward", "render_forward": "k_render_forward"}.get(dom, dom)
+            kname = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>"}.get(dom, dom)
             scale = VPC / float(pmc.get("views_per_launch", 1))      # the profile's launches covered that many views each
             traffic = pmc.get("bytes_per_launch", {}).get(kname)
             valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)

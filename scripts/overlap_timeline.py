@@ -31,5 +31,5 @@ for s, e, n, q in rows:
 print("%-28s %6s %10s %10s" % ("kernel", "calls", "avg_us", "total_ms"))
 for n in sorted(dur, key=lambda n: -sum(dur[n]))[:14]:
     print("%-28s %6d %10.1f %10.2f" % (n[:28], len(dur[n]), sum(dur[n]) / len(dur[n]) / 1e3, sum(dur[n]) / 1e6))
-frames = len(dur.get("k_render_backward", [])) or len(dur.get("k_render_forward", []))
+frames = len(dur.get("k_render_backward", [])) or len(dur.get("k_render_forward<0>", []))
 print("frames in window: %d -> %.3f ms/frame" % (frames, span / 1e6 / max(frames, 1)))
