@@ -27,6 +27,35 @@ __device__ __forceinline__ void agent_store(uint64_t* p, uint64_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef GSR_STATS
+// instrumentation build only: per-phase time of the emission workgroups (wall_clock64 ticks of 10 ns, summed over workgroups):
+// 0 ticket, 1 order + rectangle gather + scan, 2 publish -> look-back done, 3 emission; out8[4] = workgroups seen
+// one record per workgroup (no atomics: 190 K same-address atomics quadruple the kernel's time and end up being what is measured)
+constexpr int DUP_REC = 65536;
+__device__ unsigned g_dup_rec[DUP_REC][4];
+#define DUP_T(var) const unsigned long long var = wall_clock64()
+#define DUP_ADD(i, v) do { if (threadIdx.x == 0) { const unsigned r_ = blockIdx.y * gridDim.x + s_ticket; if (r_ < DUP_REC) g_dup_rec[r_][i] = (unsigned)(v); } } while (0)
+int debug_dup_times(unsigned long long* out8, int reset)
+{
+    static unsigned host[DUP_REC][4];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dup_rec), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int r = 0; r < DUP_REC; r++) {
+        if (host[r][0] == 0 && host[r][1] == 0) continue;
+        for (int i = 0; i < 4; i++) out8[i] += host[r][i];
+        out8[4]++;
+    }
+    if (reset) {
+        for (int r = 0; r < DUP_REC; r++) for (int i = 0; i < 4; i++) host[r][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dup_rec), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define DUP_T(var) do { } while (0)
+#define DUP_ADD(i, v) do { } while (0)
+#endif
+
 struct DupArgs {
     int P;
     uint32_t gridx;
@@ -53,33 +82,56 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     const uint32_t view = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t* status = at_view(a.dup_status, a.g_stride, view);
-    // Which 256 Gaussians this workgroup takes is decided by a ticket drawn when it STARTS: a workgroup with a lower number
+    // Which DUP_BLOCK Gaussians this workgroup takes is decided by a ticket drawn when it STARTS: a workgroup with a lower number
     // has started earlier, so the look-back below only ever waits for workgroups that are already running or done, whatever
     // order the hardware dispatches blockIdx in (HIP promises none).  The ticket word follows the status words.
     const uint32_t nblk = gridDim.x;
+    DUP_T(t0);
     if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long*)&status[nblk], 1ull);
     __syncthreads();
+    DUP_T(t1);
+    DUP_ADD(0, t1 - t0);
     const uint32_t blk = s_ticket;
-    const int slot = (int)(blk * DUP_THREADS + threadIdx.x);  // position in depth order
     const uint32_t* order = at_view(a.order, a.g_stride, view);
     const Splat* splat = at_view(a.splat, a.g_stride, view);
 
-    uint32_t cnt = 0, id = 0;
-    uint2 rc = make_uint2(0, 0);
-    if (slot < a.P) {
-        id = order[slot];
-        const float4 q3 = splat[id].q3;   // one 16-B gather: tile rectangle + tile count
-        rc = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
-        cnt = __float_as_uint(q3.z);
-    }
-    // ---- prefix sum: inside the wave, over the workgroup's waves, over the preceding workgroups ----
-    uint64_t inc64 = cnt;   // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: sums are carried in 64 bits
+    // A wave owns DUP_G groups of 64 consecutive Gaussians (positions in depth order); the G gathers are independent and in
+    // flight together, and the ticket and the look-back -- round trips to the fabric that bound a workgroup's life -- are paid
+    // once per DUP_G * 256 Gaussians.
+    uint32_t cnt[DUP_G], id[DUP_G];
+    uint2 rc[DUP_G];
+    const int slot0 = (int)(blk * DUP_BLOCK + w * (64 * DUP_G) + lane);
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc64, d, 64);
-        if (lane >= (uint32_t)d) inc64 += n;
+    for (int g = 0; g < DUP_G; g++) {
+        const int slot = slot0 + g * 64;
+        id[g] = slot < a.P ? order[slot] : 0u;
     }
-    if (lane == 63) s_wave[w] = inc64;
+#pragma unroll
+    for (int g = 0; g < DUP_G; g++) {
+        cnt[g] = 0;
+        rc[g] = make_uint2(0, 0);
+        if (slot0 + g * 64 < a.P) {
+            const float4 q3 = splat[id[g]].q3;   // one 16-B gather: tile rectangle + tile count
+            rc[g] = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
+            cnt[g] = __float_as_uint(q3.z);
+        }
+    }
+    // ---- prefix sum: inside the wave (group after group), over the workgroup's waves, over the preceding workgroups ----
+    // a Gaussian touches < 2^28 tiles and 64 of them < 2^34: sums are carried in 64 bits
+    uint64_t excl[DUP_G];          // exclusive prefix of this Gaussian inside the wave
+    uint64_t run = 0;              // pairs of the wave's groups so far (wave uniform)
+#pragma unroll
+    for (int g = 0; g < DUP_G; g++) {
+        uint64_t inc64 = cnt[g];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t n = (uint64_t)__shfl_up((unsigned long long)inc64, d, 64);
+            if (lane >= (uint32_t)d) inc64 += n;
+        }
+        excl[g] = run + inc64 - cnt[g];
+        run += (uint64_t)__shfl((unsigned long long)inc64, 63, 64);
+    }
+    if (lane == 63) s_wave[w] = run;
     __syncthreads();
     uint64_t wave_base = 0;
 #pragma unroll
@@ -87,20 +139,33 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
         if ((uint32_t)i < w) wave_base += s_wave[i];
     const uint64_t block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     if (threadIdx.x == 0) agent_store(&status[blk], block_total + 1);
+    DUP_T(t2);
+    DUP_ADD(1, t2 - t1);
     // look-back: every preceding workgroup's count (published as count + 1; 0 = not yet).  They were dispatched before
     // this one, so waiting for them cannot deadlock.
     uint64_t part = 0;
-    for (uint32_t b = threadIdx.x; b < blk; b += DUP_THREADS) {
-        uint64_t v;
-        uint32_t spins = 0;
-        do {
-            v = agent_load(&status[b]);
-            if (v == 0 && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
-                at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
-                v = 1;
+    // LB words per thread are requested back to back (one round trip to the fabric instead of LB); a word that has not been
+    // published yet is polled afterwards.
+    constexpr uint32_t LB = 4;
+    for (uint32_t b0 = threadIdx.x; b0 < blk; b0 += DUP_THREADS * LB) {
+        uint64_t v[LB];
+#pragma unroll
+        for (uint32_t k = 0; k < LB; k++) {
+            const uint32_t b = b0 + k * DUP_THREADS;
+            v[k] = b < blk ? agent_load(&status[b]) : 1ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < LB; k++) {
+            uint32_t spins = 0;
+            while (v[k] == 0) {
+                v[k] = agent_load(&status[b0 + k * DUP_THREADS]);
+                if (v[k] == 0 && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
+                    at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
+                    v[k] = 1;
+                }
             }
-        } while (v == 0);
-        part += v - 1;
+            part += v[k] - 1;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += (uint64_t)__shfl_xor((unsigned long long)part, d, 64);
@@ -113,41 +178,57 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
         if (blk == nblk - 1) at_view(a.counters, a.g_stride, view)[CNT_NUM_RENDERED] = base + block_total;
     }
     __syncthreads();
+    DUP_T(t3);
+    DUP_ADD(2, t3 - t2);
     if (a.keys == nullptr) return;   // count-only call (no binning arena yet)
-    const uint64_t off64 = s_base + wave_base + (inc64 - cnt);   // exclusive prefix of this Gaussian
     KeyT* keys = at_view((KeyT*)a.keys, a.b_stride, view);
     uint32_t* vals = at_view(a.vals, a.b_stride, view);
+    const uint64_t wave_off = s_base + wave_base;
 
-    // the wave's output range [wave_begin, wave_end); positions at or beyond the capacity are dropped
-    const uint64_t wave_begin64 = (uint64_t)__shfl((unsigned long long)off64, 0, 64);
-    const uint64_t wave_end64 = (uint64_t)__shfl((unsigned long long)(off64 + cnt), 63, 64);
-    if (wave_begin64 >= (uint64_t)a.cap) return;
-    const uint32_t wave_begin = (uint32_t)wave_begin64;
-    const uint32_t wave_end = wave_end64 < (uint64_t)a.cap ? (uint32_t)wave_end64 : (uint32_t)a.cap;   // cap < 2^32
-    // offsets relative to the wave's begin (fit 32 bits: 64 Gaussians x < 2^28 tiles is rejected by the host long before)
-    uint32_t off = (uint32_t)(off64 - wave_begin64);
-    s_off[w][lane] = off;
-    s_id[w][lane] = id;
-    s_rect[w][lane] = rc;
-    __builtin_amdgcn_wave_barrier();
-
-    for (uint32_t p = wave_begin + lane; p < wave_end; p += 64) {
-        const uint32_t rel = p - wave_begin;
-        // largest s with s_off[s] <= rel  (offsets are non-decreasing; zero-count entries are skipped)
-        uint32_t lo = 0;
+#pragma unroll 1
+    for (int g = 0; g < DUP_G; g++) {
+        // select group g's registers without dynamic indexing
+        uint32_t cnt_g = cnt[0], id_g = id[0];
+        uint2 rc_g = rc[0];
+        uint64_t ex_g = excl[0];
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const uint32_t cand = lo + step;
-            if (cand < 64 && s_off[w][cand] <= rel) lo = cand;
+        for (int k = 1; k < DUP_G; k++)
+            if (g == k) { cnt_g = cnt[k]; id_g = id[k]; rc_g = rc[k]; ex_g = excl[k]; }
+        const uint64_t off64 = wave_off + ex_g;   // exclusive prefix of this Gaussian
+        // the group's output range [grp_begin, grp_end); positions at or beyond the capacity are dropped
+        const uint64_t grp_begin64 = (uint64_t)__shfl((unsigned long long)off64, 0, 64);
+        const uint64_t grp_end64 = (uint64_t)__shfl((unsigned long long)(off64 + cnt_g), 63, 64);
+        if (grp_begin64 >= (uint64_t)a.cap) break;
+        const uint32_t grp_begin = (uint32_t)grp_begin64;
+        const uint32_t grp_end = grp_end64 < (uint64_t)a.cap ? (uint32_t)grp_end64 : (uint32_t)a.cap;   // cap < 2^32
+        // offsets relative to the group's begin (fit 32 bits: 64 Gaussians x < 2^28 tiles is rejected by the host long before)
+        __builtin_amdgcn_wave_barrier();   // the previous group's reads of the staging arrays are done
+        s_off[w][lane] = (uint32_t)(off64 - grp_begin64);
+        s_id[w][lane] = id_g;
+        s_rect[w][lane] = rc_g;
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t p = grp_begin + lane; p < grp_end; p += 64) {
+            const uint32_t rel = p - grp_begin;
+            // largest s with s_off[s] <= rel  (offsets are non-decreasing; zero-count entries are skipped)
+            uint32_t lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const uint32_t cand = lo + step;
+                if (cand < 64 && s_off[w][cand] <= rel) lo = cand;
+            }
+            const uint2 r = s_rect[w][lo];
+            const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
+            const uint32_t width = maxx - minx;
+            const uint32_t t = rel - s_off[w][lo];
+            const uint32_t row = t / width, col = t - row * width;
+            keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
+            vals[p] = s_id[w][lo];
         }
-        const uint2 r = s_rect[w][lo];
-        const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
-        const uint32_t width = maxx - minx;
-        const uint32_t t = rel - s_off[w][lo];
-        const uint32_t row = t / width, col = t - row * width;
-        keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
-        vals[p] = s_id[w][lo];
     }
+#ifdef GSR_STATS
+    if (w == 0) { DUP_T(t4); DUP_ADD(3, t4 - t3); }
+#endif
 }
 
 int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16)
@@ -164,7 +245,7 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     a.vals = B.b.val[0];
     a.b_stride = B.b_stride;
     a.cap = B.b.key[0] ? B.b.cap : 0;
-    const dim3 grid((unsigned)div_up(P, DUP_THREADS), B.V);
+    const dim3 grid((unsigned)div_up(P, DUP_BLOCK), B.V);
     if (key16)
         hipLaunchKernelGGL(k_duplicate<uint16_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);
     else

@@ -39,6 +39,11 @@ constexpr int RADIX = 1 << RADIX_BITS;
 inline int sort_hist_stride(int64_t n) { return (int)(((n + RS_TILE - 1) / RS_TILE + 15) / 16 * 16); }
 
 constexpr int DUP_THREADS = 256;  // Gaussians per pair-emission workgroup (binning.hip)
+#ifndef GSR_DUP_G
+#define GSR_DUP_G 4
+#endif
+constexpr int DUP_G = GSR_DUP_G;                    // Gaussians per thread of the pair emission
+constexpr int DUP_BLOCK = DUP_THREADS * DUP_G;     // Gaussians per emission workgroup (one ticket, one look-back)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -281,6 +286,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
 int selftest_reduce(hipStream_t stream, float* d_scratch128);
 #ifdef GSR_STATS
 int debug_bwd_stats(unsigned long long* out8, int reset);   // instrumentation build only
+int debug_dup_times(unsigned long long* out8, int reset);
 #endif
 // preprocess_bwd.hip
 // reads grad_rec of every view; writes the user-facing gradients summed over the views of the batch

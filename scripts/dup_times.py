@@ -1,0 +1,39 @@
+"""Instrumentation run (library built with GSR_EXTRA_FLAGS=-DGSR_STATS): where an emission workgroup's time goes."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gaussian-pcloud-render_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from pcrender import camera, synth
+from diff_gaussian_rasterization import _native as N
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_batch as TB
+dev = torch.device("cuda:0")
+cloud = synth.make_cloud("synth-THuman-800K", seed=0)
+g = synth.make_gaussians(cloud, profile="training", seed=1)
+views = camera.circle_views(12, fov_deg=45.0, width_px=1920, height_px=1080)
+out = (C.c_ulonglong * 8)()
+for V in (1, 12):
+    args = TB._batch_args(g, views[:V], 1920, 1080, dev)
+    for _ in range(2):
+        N.rasterize_gaussians_batch(*args, need_backward=False)
+    torch.cuda.synchronize()
+    N.lib.gsr_debug_dup_times(out, 1)
+    N.rasterize_gaussians_batch(*args, need_backward=False)
+    torch.cuda.synchronize()
+    N.lib.gsr_debug_dup_times(out, 0)
+    n = max(int(out[4]), 1)
+    us = [int(out[i]) * 0.01 / n for i in range(4)]
+    print("V=%d: workgroups %d; mean us per workgroup: ticket %.2f, order+gather+scan %.2f, look-back %.2f, emission %.2f (sum %.2f)"
+          % (V, n, us[0], us[1], us[2], us[3], sum(us)))
+# cross-check against the stage's own duration
+N.set_profiling(True)
+args = TB._batch_args(g, views[:12], 1920, 1080, dev)
+N.lib.gsr_debug_dup_times(out, 1)
+N.rasterize_gaussians_batch(*args, need_backward=False)
+torch.cuda.synchronize()
+N.lib.gsr_debug_dup_times(out, 0)
+prof = dict(N.get_profile()); N.set_profiling(False)
+ticks = sum(int(out[i]) for i in range(4))
+print("duplicate stage %.3f ms; summed workgroup lifetimes %d ticks over %d workgroups; if 2048 were resident throughout: %.1f ns per tick"
+      % (prof["duplicate"], ticks, int(out[4]), prof["duplicate"] * 1e6 * 2048 / ticks))
