@@ -139,6 +139,34 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+#ifdef GSR_STATS
+// instrumentation build only: per-phase time of the scatter workgroups of the LAST launch (one record per workgroup, 10-ns ticks):
+// 0 keys/values loaded, 1 ranking, 2 prefix sums, 3 reorder in LDS, 4 stores issued
+constexpr int SC_REC = 65536;
+__device__ unsigned g_sc_rec[SC_REC][5];
+#define SC_T(var) const unsigned long long var = wall_clock64()
+#define SC_PUT(i, v) do { if (threadIdx.x == 0) { const unsigned r_ = blockIdx.y * gridDim.x + blockIdx.x; if (r_ < SC_REC) g_sc_rec[r_][i] = (unsigned)(v); } } while (0)
+int debug_scatter_times(unsigned long long* out8, int reset)
+{
+    static unsigned host[SC_REC][5];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sc_rec), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int r = 0; r < SC_REC; r++) {
+        if (host[r][1] == 0) continue;
+        for (int i = 0; i < 5; i++) out8[i] += host[r][i];
+        out8[5]++;
+    }
+    if (reset) {
+        for (int r = 0; r < SC_REC; r++) for (int i = 0; i < 5; i++) host[r][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sc_rec), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define SC_T(var) do { } while (0)
+#define SC_PUT(i, v) do { } while (0)
+#endif
+
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
 template <int BITS, typename KeyT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
@@ -173,6 +201,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     const int64_t seg_base = blk_base + (int64_t)w * (RS_TILE / RS_WAVES);
 
     for (int i = lane; i < RADIX; i += 64) wave_cnt[w][i] = 0;
+    SC_T(t0);
+
+    // requested before the keys (loads return in order): see gbase_d below
+    const uint32_t tot_d = tid <= mask ? totals[tid] : 0u;
+    const uint32_t hist_d = tid <= mask ? hist[(size_t)tid * nblk_pad + blk] : 0u;
 
     uint32_t k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
     const bool full = blk_base + RS_TILE <= n;   // all but the last block of a view: no bounds checks
@@ -199,7 +232,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             }
         }
     }
+    // digit d = tid: first global slot of this workgroup's digit-d run = digits below d in the whole array + digit d in the
+    // blocks before this one.  Needs nothing from the keys: the two loads and the scan overlap the key loads' latency instead
+    // of sitting between ranking and reorder (a fifth of the workgroup's life there, scripts/dup_times.py).
+    const uint32_t gbase_d = block_exclusive_scan_256(tot_d, tmp, nullptr) + hist_d;
     __builtin_amdgcn_wave_barrier();
+#ifdef GSR_STATS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SC_T(t1);
+    SC_PUT(0, t1 - t0);
 
     // stable rank inside the wave's segment: order is (j, lane).  peers = the lanes holding my digit: one ballot per digit
     // bit, folded in with one three-input bit operation per half (peers & ~(ballot ^ my bit)); the count of peers below me
@@ -225,6 +267,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    SC_T(t2);
+    SC_PUT(1, t2 - t1);
 
     // digit d = tid: exclusive prefix over waves, workgroup-local and global run starts
     {
@@ -238,10 +282,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
         }
         const uint32_t lb = block_exclusive_scan_256(run, tmp, nullptr);
         local_base[d] = lb;
-        const uint32_t gt = block_exclusive_scan_256(d <= mask ? totals[d] : 0u, tmp, nullptr);
-        global_base[d] = d <= mask ? gt + hist[(size_t)d * nblk_pad + blk] : 0u;
+        global_base[d] = gbase_d;
     }
     __syncthreads();
+    SC_T(t3);
+    SC_PUT(2, t3 - t2);
 
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
@@ -253,6 +298,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
         }
     }
     __syncthreads();
+    SC_T(t4);
+    SC_PUT(3, t4 - t3);
 
     const int64_t rem = n - blk_base;
     const uint32_t count = rem < RS_TILE ? (uint32_t)rem : (uint32_t)RS_TILE;
@@ -267,6 +314,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             vals_out[g] = s_val[p];
         }
     }
+#ifdef GSR_STATS
+    { SC_T(t5); SC_PUT(4, t5 - t4); }
+#endif
 }
 
 // Sorts on key bits [0, end_bit).  job.key[0]/val[0] hold the input (val[0] ignored when iota_vals); the

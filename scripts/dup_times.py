@@ -37,3 +37,10 @@ prof = dict(N.get_profile()); N.set_profiling(False)
 ticks = sum(int(out[i]) for i in range(4))
 print("duplicate stage %.3f ms; summed workgroup lifetimes %d ticks over %d workgroups; if 2048 were resident throughout: %.1f ns per tick"
       % (prof["duplicate"], ticks, int(out[4]), prof["duplicate"] * 1e6 * 2048 / ticks))
+
+# the LAST scatter launch of the forward above = second pass of the tile sort (6-bit digit)
+N.lib.gsr_debug_scatter_times(out, 0)
+n = max(int(out[5]), 1)
+us = [int(out[i]) * 0.01 / n for i in range(5)]
+print("tile-sort scatter (last pass): workgroups %d; mean us per workgroup: loads %.2f, ranking %.2f, prefix %.2f, LDS reorder %.2f, stores %.2f (sum %.2f); stage tile_sort %.3f ms"
+      % (n, us[0], us[1], us[2], us[3], us[4], sum(us), prof["tile_sort"]))
