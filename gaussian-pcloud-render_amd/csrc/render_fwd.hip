@@ -149,9 +149,36 @@ __device__ __forceinline__ PairRec<NX> read_pair(const float* lds, int pair)
     return r;
 }
 
+#ifdef GSR_STATS
+// instrumentation build only: where the forward waves' time goes, summed over the waves of the launches since the last reset
+// (10-ns ticks): 0 whole life, 1 waiting for the next round's records at the rotation point, 2 footprint test + staging,
+// 3 pair evaluation, 4 waves, 5 rounds, 6 pairs evaluated
+// (one record per wave of the LAST launch -- same-address atomics from 390 K waves would be what gets measured)
+constexpr int FW_REC = 1 << 19;
+__device__ unsigned g_fwd_rec[FW_REC][8];
+#define FW_T(var) const unsigned long long var = wall_clock64()
+int debug_fwd_times(unsigned long long* out8, int reset)
+{
+    static unsigned host[FW_REC][8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_rec), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int r = 0; r < FW_REC; r++)
+        for (int i = 0; i < 7; i++) out8[i] += host[r][i];
+    if (reset) {
+        for (int r = 0; r < FW_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_rec), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 template <int NX>
 __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 {
+#ifdef GSR_STATS
+    FW_T(tw0);
+    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
+#endif
     static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
     constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
@@ -264,6 +291,10 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 crossed = true;
             }
 
+#ifdef GSR_STATS
+            FW_T(ts0);
+            n_rounds++;
+#endif
             // which of this round's 64 entries can reach alpha >= 1/255 somewhere in this quadrant?
             const bool valid = base + (int)lane < total;
             const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx0, by0, bx1, by1);
@@ -386,6 +417,10 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 // and the loop ends on the pair count alone: when every pixel is done the count is set to 0.
                 int npairs = (int)((nsurv + 1u) >> 1);
                 int pair = 0;
+#ifdef GSR_STATS
+                FW_T(ts1);
+                tw_stage += ts1 - ts0;
+#endif
                 PairRec<NX> ra = read_pair<NX>(stage, 0), rb;
                 for (;;) {
                     rb = read_pair<NX>(stage, pair + 1);
@@ -397,9 +432,18 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                     if (all_done) npairs = 0;
                     if (++pair >= npairs) break;
                 }
+#ifdef GSR_STATS
+                { FW_T(ts2); tw_eval += ts2 - ts1; n_pairs += (unsigned long long)pair; }
+#endif
             }
+#ifdef GSR_STATS
+            FW_T(ts3);
+#endif
             if (NX > 0) retire_prefetch_x(n0, n1, n2b, id_nn, nx0, nx1);
             else retire_prefetch(n0, n1, n2b, id_nn);
+#ifdef GSR_STATS
+            { FW_T(ts4); tw_wait += ts4 - ts3; }
+#endif
             if (all_done) break;
             c0 = n0; c1 = n1; c2b = n2b;
             if (NX > 0) { cx0 = nx0; cx1 = nx1; }
@@ -408,6 +452,14 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         }
     }
 
+#ifdef GSR_STATS
+    if (lane == 0 && blockIdx.x < (unsigned)FW_REC) {
+        FW_T(tw1);
+        unsigned* r_ = g_fwd_rec[blockIdx.x];
+        r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_stage; r_[3] = (unsigned)tw_eval;
+        r_[4] = 1u; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_pairs;
+    }
+#endif
     // instrumentation: how many list entries this tile really needed (max over its pixels); tile_need is zeroed
     // before the launch
     {

@@ -44,3 +44,16 @@ n = max(int(out[5]), 1)
 us = [int(out[i]) * 0.01 / n for i in range(5)]
 print("tile-sort scatter (last pass): workgroups %d; mean us per workgroup: loads %.2f, ranking %.2f, prefix %.2f, LDS reorder %.2f, stores %.2f (sum %.2f); stage tile_sort %.3f ms"
       % (n, us[0], us[1], us[2], us[3], us[4], sum(us), prof["tile_sort"]))
+
+# forward render waves (atomics at wave exit only: 390 K per launch, after the work)
+N.lib.gsr_debug_fwd_times(out, 1)
+N.set_profiling(True)
+N.rasterize_gaussians_batch(*args, need_backward=True)
+torch.cuda.synchronize()
+prof = dict(N.get_profile()); N.set_profiling(False)
+N.lib.gsr_debug_fwd_times(out, 0)
+life, wait, stage, ev, waves, rounds, pairs = [int(out[i]) for i in range(7)]
+print("forward render: %d waves, %d rounds, %d pairs; wave time %.1f ms-waves: waiting for records %.1f %%, footprint test + staging %.1f %%, pair evaluation %.1f %%, rest %.1f %%; "
+      "%.2f us per round waiting, %.3f us per pair; stage %.3f ms"
+      % (waves, rounds, pairs, life * 1e-5, 100.0 * wait / life, 100.0 * stage / life, 100.0 * ev / life, 100.0 * (life - wait - stage - ev) / life,
+         wait * 0.01 / max(rounds, 1), ev * 0.01 / max(pairs, 1), prof["render_forward"]))
