@@ -196,13 +196,39 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
     return 0;
 }
 
-#ifdef GSR_STATS
-// instrumentation build only (GSR_EXTRA_FLAGS=-DGSR_STATS): 0 rounds, 1 staged entries, 2 groups, 3 groups with a hit,
+#if defined(GSR_STATS) && defined(GSR_STATS_HITS)
+// instrumentation build only (GSR_EXTRA_FLAGS="-DGSR_STATS -DGSR_STATS_HITS"; the atomics slow the kernel 100x, so they are
+// kept out of the timing build): 0 rounds, 1 staged entries, 2 groups, 3 groups with a hit,
 // 4 entries with a hit, 5 (pixel, entry) hits
 __device__ unsigned long long g_bwd_stats[8];
 #define BWD_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bwd_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define BWD_STAT(i, v) do { } while (0)
+#ifdef GSR_STATS
+__device__ unsigned long long g_bwd_stats[8];
+#endif
+#endif
+
+#ifdef GSR_STATS
+// per-workgroup (= wave) time split of the LAST backward launch, 10-ns ticks: 0 whole life, 1 waiting at the rotation point
+// (next round's records AND this round's atomics: stores count in vmcnt on gfx9), 2 item set-up (per-pixel state, first
+// records), 3 footprint test + staging, 4 group evaluation + reduction + atomics issue, 5 rounds, 6 groups, 7 items
+constexpr int BW_REC = 1 << 17;
+__device__ unsigned g_bwd_rec[BW_REC][8];
+#define BW_T(var) const unsigned long long var = wall_clock64()
+int debug_bwd_times(unsigned long long* out8, int reset)
+{
+    static unsigned host[BW_REC][8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_rec), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int r = 0; r < BW_REC; r++)
+        for (int i = 0; i < 8; i++) out8[i] += host[r][i];
+    if (reset) {
+        for (int r = 0; r < BW_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_rec), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 struct RenderBwdArgs {
@@ -243,7 +269,15 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
     __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
+#ifdef GSR_STATS
+    BW_T(tw0);
+    unsigned long long tw_wait = 0, tw_setup = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_groups = 0, n_items_done = 0;
+#endif
   for (uint32_t item_idx = (group / a.V) * 8u + (blockIdx.x & 7u); item_idx < n_items; item_idx += groups_per_view * 8u) {
+#ifdef GSR_STATS
+    BW_T(ti0);
+    n_items_done++;
+#endif
     const uint32_t item = a.items[item_idx];
     const uint32_t tile = item & ((1u << BWD_TILE_BITS) - 1u), chunk = item >> BWD_TILE_BITS;
     const uint32_t q = (blockIdx.x >> 3) & 3u;
@@ -341,7 +375,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         bw_prefetch4f(c2b, &sp->q2);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2b)::"memory");
     }
+#ifdef GSR_STATS
+    { BW_T(ti1); tw_setup += ti1 - ti0; }
+#endif
     for (int hi = hi0; hi > lo; hi -= 64) {
+#ifdef GSR_STATS
+        BW_T(tr0);
+        n_rounds++;
+#endif
         {
             const Splat* sp = a.splat + id_nxt;
             bw_prefetch16(n0, &sp->q0);
@@ -377,8 +418,15 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         BWD_STAT(0, 1);
         BWD_STAT(1, __popcll(mask));
         int quad = 0;
+#ifdef GSR_STATS
+        BW_T(tr1);
+        tw_stage += tr1 - tr0;
+#endif
         while (mask != 0) {
             BWD_STAT(2, 1);
+#ifdef GSR_STATS
+            n_groups++;
+#endif
             float ex[BGRP], ey[BGRP], eA[BGRP], eB[BGRP], eC[BGRP], eo[BGRP], er[BGRP], eg[BGRP], eb[BGRP];
             uint32_t ef[BGRP];
             {
@@ -420,7 +468,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 any_lane_hit = any_lane_hit || hits[k] || hits[k + 1];
             }
             if (!__any(any_lane_hit)) continue;
-#ifdef GSR_STATS
+#if defined(GSR_STATS) && defined(GSR_STATS_HITS)
             BWD_STAT(3, 1);
             for (int k = 0; k < BGRP; k++) {
                 const uint64_t hm = __ballot(hits[k]);
@@ -494,12 +542,27 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t id = __builtin_bit_cast(uint32_t, stage[(quad - 1) * QUAD_WORDS + 36 + tgt_k]);
             if (tgt_on && val != 0.f) atomicAdd(a.grad_rec + (size_t)id * GRAD_REC_WORDS + tgt_c, val);
         }
+#ifdef GSR_STATS
+        BW_T(tr2);
+        tw_eval += tr2 - tr1;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2b), "+v"(id_nn)::"memory");
+#ifdef GSR_STATS
+        { BW_T(tr3); tw_wait += tr3 - tr2; }
+#endif
         c0 = n0; c1 = n1; c2b = n2b;
         id_cur = id_nxt;
         id_nxt = id_nn;
     }
   }
+#ifdef GSR_STATS
+    if (threadIdx.x == 0 && blockIdx.x < (unsigned)BW_REC) {
+        BW_T(tw1);
+        unsigned* r_ = g_bwd_rec[blockIdx.x];
+        r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_setup; r_[3] = (unsigned)tw_stage;
+        r_[4] = (unsigned)tw_eval; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_groups; r_[7] = (unsigned)n_items_done;
+    }
+#endif
 }
 
 #ifdef GSR_STATS

@@ -1,4 +1,4 @@
-"""Instrumentation run (library built with GSR_EXTRA_FLAGS=-DGSR_STATS): how much of the render backward's staged work hits."""
+"""Instrumentation run (library built with GSR_EXTRA_FLAGS="-DGSR_STATS -DGSR_STATS_HITS"): how much of the render backward's staged work hits."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gaussian-pcloud-render_amd"), os.path.join(ROOT, "tests")):

@@ -57,3 +57,20 @@ print("forward render: %d waves, %d rounds, %d pairs; wave time %.1f ms-waves: w
       "%.2f us per round waiting, %.3f us per pair; stage %.3f ms"
       % (waves, rounds, pairs, life * 1e-5, 100.0 * wait / life, 100.0 * stage / life, 100.0 * ev / life, 100.0 * (life - wait - stage - ev) / life,
          wait * 0.01 / max(rounds, 1), ev * 0.01 / max(pairs, 1), prof["render_forward"]))
+
+# backward render waves
+counts, color, radii, geom, binning, img = N.rasterize_gaussians_batch(*args, need_backward=True)
+dL = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (12, 3, 1080, 1920)).astype(np.float32)).to(dev)
+N.lib.gsr_debug_bwd_times(out, 1)
+N.set_profiling(True)
+N.rasterize_gaussians_backward_batch(args[0], args[1], radii, args[2], args[4], args[5], 1.0, args[7], args[8], args[9], args[10], args[11], dL,
+                                     args[14], args[15], args[16], geom, binning, img, False)
+torch.cuda.synchronize()
+prof = dict(N.get_profile()); N.set_profiling(False)
+N.lib.gsr_debug_bwd_times(out, 0)
+life, wait, setup, stage, ev, rounds, groups, items = [int(out[i]) for i in range(8)]
+print("backward render: %d items, %d rounds, %d groups of 4 entries; wave time %.1f ms-waves: item set-up %.1f %%, footprint test + staging %.1f %%, groups %.1f %%, "
+      "wait at rotation %.1f %%, rest (idle tail, loop) %.1f %%; %.2f us per group, %.2f us wait per round, %.2f us set-up per item; stage %.3f ms"
+      % (items, rounds, groups, life * 1e-5, 100.0 * setup / life, 100.0 * stage / life, 100.0 * ev / life, 100.0 * wait / life,
+         100.0 * (life - wait - setup - stage - ev) / life, ev * 0.01 / max(groups, 1), wait * 0.01 / max(rounds, 1), setup * 0.01 / max(items, 1),
+         prof["render_backward"]))
