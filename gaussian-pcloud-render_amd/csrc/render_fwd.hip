@@ -162,8 +162,10 @@ int debug_fwd_times(unsigned long long* out8, int reset)
     static unsigned host[FW_REC][8];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_rec), sizeof(host)) != hipSuccess) return -1;
     for (int i = 0; i < 8; i++) out8[i] = 0;
-    for (int r = 0; r < FW_REC; r++)
+    for (int r = 0; r < FW_REC; r++) {
         for (int i = 0; i < 7; i++) out8[i] += host[r][i];
+        if (host[r][0] > out8[7]) out8[7] = host[r][0];   // the longest-lived wave
+    }
     if (reset) {
         for (int r = 0; r < FW_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_rec), host, sizeof(host)) != hipSuccess) return -1;
