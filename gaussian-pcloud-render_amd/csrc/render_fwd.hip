@@ -22,6 +22,10 @@
 // instruction per ~5.5 cycles when it has its SIMD to itself); tiles are dispatched in descending list-length order
 // (tile_order).  With need_backward the per-pixel (T, C) state is left at every BWD_CHUNK-entry boundary a quadrant
 // crosses, so that the backward pass can work on slices of lists (render_bwd.hip).
+//
+// k_render_forward<NX>, NX = 4 or 8: the same walk also composites NX extra per-Gaussian channels with the colour's alphas
+// (gsr_forward_batch_channels: the reference's callers render world xyz, a hit map and normals as three more full passes,
+// simple_raw_render.py:410-524).  The extra values ride in the pair records next to the colour; NX = 0 is the plain kernel.
 #include "common.hpp"
 #include "tile_cull.hpp"
 
