@@ -85,8 +85,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
     // HIST_COPIES private histograms (four per wave, by lane mod 4): same-digit keys of one wave instruction serialise in
     // the LDS atomic unit, the copies quarter those collisions
     constexpr int HIST_COPIES = 4 * RS_WAVES;
-    __shared__ uint32_t h[HIST_COPIES][RADIX];
-    for (int i = threadIdx.x; i < HIST_COPIES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
+    __shared__ __attribute__((aligned(16))) uint32_t h[HIST_COPIES][RADIX];
+    for (int i = threadIdx.x; i < HIST_COPIES * RADIX / 4; i += RS_THREADS) reinterpret_cast<uint4*>(&h[0][0])[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const uint32_t w = (threadIdx.x >> 6) * 4u + (threadIdx.x & 3u);
