@@ -221,8 +221,14 @@ int debug_bwd_times(unsigned long long* out8, int reset)
     static unsigned host[BW_REC][8];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_rec), sizeof(host)) != hipSuccess) return -1;
     for (int i = 0; i < 8; i++) out8[i] = 0;
-    for (int r = 0; r < BW_REC; r++)
+    unsigned long long longest = 0, waves = 0;
+    for (int r = 0; r < BW_REC; r++) {
         for (int i = 0; i < 8; i++) out8[i] += host[r][i];
+        if (host[r][0] > longest) longest = host[r][0];
+        if (host[r][0] != 0) waves++;
+    }
+    out8[5] = longest;   // (rounds are not reported any more) the longest-lived wave
+    out8[7] = (out8[7] << 20) | waves;   // items in the upper bits, waves that ran in the lower 20
     if (reset) {
         for (int r = 0; r < BW_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_rec), host, sizeof(host)) != hipSuccess) return -1;

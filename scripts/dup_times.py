@@ -68,9 +68,10 @@ N.rasterize_gaussians_backward_batch(args[0], args[1], radii, args[2], args[4], 
 torch.cuda.synchronize()
 prof = dict(N.get_profile()); N.set_profiling(False)
 N.lib.gsr_debug_bwd_times(out, 0)
-life, wait, setup, stage, ev, rounds, groups, items = [int(out[i]) for i in range(8)]
-print("backward render: %d items, %d rounds, %d groups of 4 entries; wave time %.1f ms-waves: item set-up %.1f %%, footprint test + staging %.1f %%, groups %.1f %%, "
-      "wait at rotation %.1f %%, rest (idle tail, loop) %.1f %%; %.2f us per group, %.2f us wait per round, %.2f us set-up per item; stage %.3f ms"
-      % (items, rounds, groups, life * 1e-5, 100.0 * setup / life, 100.0 * stage / life, 100.0 * ev / life, 100.0 * wait / life,
-         100.0 * (life - wait - setup - stage - ev) / life, ev * 0.01 / max(groups, 1), wait * 0.01 / max(rounds, 1), setup * 0.01 / max(items, 1),
-         prof["render_backward"]))
+life, wait, setup, stage, ev, longest, groups, packed = [int(out[i]) for i in range(8)]
+items, waves = packed >> 20, packed & ((1 << 20) - 1)
+k = prof["render_backward"]
+print("backward render: %d items over %d waves, %d groups of 4 entries; wave time %.1f ms-waves: item set-up %.1f %%, footprint test + staging %.1f %%, groups %.1f %%, "
+      "wait at rotation %.1f %%, rest %.1f %%; %.2f us per group; stage %.3f ms, mean wave life %.3f ms, longest %.3f ms, mean occupancy %.0f waves"
+      % (items, waves, groups, life * 1e-5, 100.0 * setup / life, 100.0 * stage / life, 100.0 * ev / life, 100.0 * wait / life,
+         100.0 * (life - wait - setup - stage - ev) / life, ev * 0.01 / max(groups, 1), k, life * 1e-5 / max(waves, 1), longest * 1e-5, life * 1e-5 / k))
