@@ -91,6 +91,19 @@ def rasterize_views(means3D_list, opacity_list, scales_list, rotations_list, H_c
     return _finish(frames, batchsize, num_q, h, w, super_sample_rate)
 
 
+def normal_view_signs(means3D, normals, cam_origins):
+    """The factors c_j with which the reference's per-view loop (simple_raw_render.py:264-268) ends up multiplying the normals
+    of view j: sgn_j = +1 iff (p0 - cam_j) . (c_(j-1) n0) > 0 for the FIRST point, c_j = -c_(j-1) * sgn_j, c_(-1) = 1.
+    One reduction over the q camera origins instead of q rounds of full-array kernels."""
+    dots = torch.sum((means3D[0:1] - cam_origins) * normals[0:1], -1).cpu()      # [q], the reference's expression for point 0
+    c, cs = 1.0, []
+    for j in range(cam_origins.shape[0]):
+        sgn = 1.0 if float(dots[j]) * c > 0 else -1.0
+        c = c * (-1.0) * sgn
+        cs.append(c)
+    return cs
+
+
 @torch.no_grad()
 def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, bg, scale_factor, normals=None, sh_degree=1,
                   super_sample_rate=2):
@@ -122,13 +135,7 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
         # carries the flipped array into the next view: colours_j = c_j * normals with c_j = -c_(j-1) * sgn_j, sgn_j = +1 iff
         # (p0 - cam_j) . (c_(j-1) n0) > 0.  Multiplying by +-1 is exact, so the scalars c_j follow from the q dot products of
         # the first point alone.
-        cam_orig = packed[:, 35:38]
-        dots = torch.sum((means3D[0:1] - cam_orig) * normals[0:1], -1).cpu()      # [q], the reference's expression for point 0
-        c, cs = 1.0, []
-        for j in range(num_q):
-            sgn = 1.0 if float(dots[j]) * c > 0 else -1.0
-            c = c * (-1.0) * sgn
-            cs.append(c)
+        cs = normal_view_signs(means3D, normals, packed[:, 35:38])
     bg_cpu = bg if (bg is not None and bg.device.type == "cpu") else bg_d.cpu()
     if float(bg_cpu[0]) == float(bg_cpu[1]) == float(bg_cpu[2]):
         # ONE render for the four passes: world xyz, the hit map's single channel and the normals ride along as extra channels

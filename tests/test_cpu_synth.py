@@ -42,3 +42,23 @@ def test_batched_view_settings_are_bit_identical_to_per_view():
         assert a["tanfovx"] == b["tanfovx"] and a["tanfovy"] == b["tanfovy"]
         for k in ("viewmatrix", "projmatrix", "campos"):
             assert torch.equal(a[k], b[k][j]), (k, j)
+
+
+def test_normal_view_signs_match_the_reference_loop():
+    """raster_passes.normal_view_signs against the literal per-view loop of simple_raw_render.py:264-268 (CPU tensors)."""
+    import torch
+    from pcrender import camera, raster_passes as rp
+    g = torch.Generator().manual_seed(5)
+    Hs = camera.circle_path(12, 0, 3, [90, 0])
+    for trial in range(20):
+        means = torch.randn(50, 3, generator=g)
+        normals = torch.nn.functional.normalize(torch.randn(50, 3, generator=g), dim=-1)
+        if trial == 0:
+            normals[0] = 0.0                     # the dot product of the first point is exactly 0 in every view
+        cams = Hs[:, :3, 3]
+        cs = rp.normal_view_signs(means, normals, cams)
+        colors = normals
+        for j in range(12):
+            sgn = (torch.sum((means - cams[j]) * colors, -1, keepdim=True) > 0).float() * 2 - 1
+            colors = colors * (-1) * sgn[0]
+            assert torch.equal(colors, normals * cs[j]), (trial, j)
