@@ -26,5 +26,5 @@ for V in (1, 12):
     N.lib.gsr_debug_fwd_times(out, 0)
     life, wait, stage, ev, waves, rounds, pairs, longest = [int(out[i]) for i in range(8)]
     k = prof["render_forward"]
-    print("V=%d: kernel %.3f ms; %d waves, summed wave time %.1f ms (mean occupancy %.0f waves of 6144 slots), longest wave %.3f ms, mean wave %.1f us; rounds %d pairs %d"
+    print("V=%d: kernel %.3f ms; %d waves, summed wave time %.1f ms (mean occupancy %.0f waves of 5120 slots (82 VGPRs: 5 waves per SIMD)), longest wave %.3f ms, mean wave %.1f us; rounds %d pairs %d"
           % (V, k, waves, life * 1e-5, life * 1e-5 / k, longest * 1e-5, life * 0.01 / waves, rounds, pairs))
