@@ -107,21 +107,31 @@ struct ProfScope {
 
 // ---- per-thread pinned landing zone for the counter read-back ------------------------------------------
 constexpr int MAX_VIEWS = 256;
+// One per (host thread, device): an event belongs to the device that was current when it was created, so a thread that
+// renders on several GPUs needs one landing zone for each.
 struct HostLanding {
     uint64_t* pinned = nullptr;   // [MAX_VIEWS][4]: num_rendered, trap flag, stall flag, -
     hipEvent_t ev = nullptr;
-    int ensure()
-    {
-        if (pinned) return GSR_OK;
-        if (hipHostMalloc((void**)&pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            pinned = nullptr;
+};
+static thread_local std::map<int, HostLanding> t_lands;
+static int landing(HostLanding** out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] hipGetDevice: %s", hipGetErrorString(hipGetLastError()));
+    HostLanding& h = t_lands[dev];
+    if (!h.pinned) {
+        if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
+            h.pinned = nullptr;
             return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
         }
-        return GSR_OK;
     }
-};
-static thread_local HostLanding t_land;
+    *out = &h;
+    return GSR_OK;
+}
+
+// device->host read-backs the library has issued since it was loaded (one per forward call: the per-view counters)
+static std::atomic<long long> g_d2h_count{0};
 
 static int tile_count(const gsr_params* p) { return ((p->W + TILE_X - 1) / TILE_X) * ((p->H + TILE_Y - 1) / TILE_Y); }
 
@@ -157,18 +167,23 @@ static int sorted_buffer(int T) { return ((tile_bits(T) + RADIX_BITS - 1) / RADI
 
 static inline void* align256(void* p) { return (void*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
 
-// Carve the caller's three allocations into V per-view arenas.  binning may be NULL (count-only forward).
+// Carve the caller's three allocations into V per-view arenas.  binning may be NULL (count-only forward).  with_grad: the
+// V gradient-record blocks that follow the V geometry arenas are part of the geometry allocation (need_backward calls).
 static int make_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
-                      size_t binning_bytes, Batch& B)
+                      size_t binning_bytes, bool with_grad, Batch& B)
 {
     B.V = V;
     const size_t G = geom_view(nullptr, p->P).bytes, I = image_view(nullptr, p->W, p->H).bytes;
-    if (!geom || geom_bytes < (size_t)V * G + 256)
-        return fail(GSR_ERR_CAPACITY, "[gsr] geom arena too small (%zu < %zu)", geom_bytes, (size_t)V * G + 256);
+    const size_t GR = with_grad ? grad_rec_bytes(p->P) : 0;
+    if (!geom || geom_bytes < (size_t)V * (G + GR) + 256)
+        return fail(GSR_ERR_CAPACITY, "[gsr] geom arena too small (%zu < %zu%s)", geom_bytes, (size_t)V * (G + GR) + 256,
+                    with_grad ? ", need_backward" : "");
     if (!image || image_bytes < (size_t)V * I + 256)
         return fail(GSR_ERR_CAPACITY, "[gsr] image arena too small (%zu < %zu)", image_bytes, (size_t)V * I + 256);
     B.g = geom_view(align256(geom), p->P);
     B.g_stride = G;
+    B.grad_rec = with_grad ? reinterpret_cast<float*>(reinterpret_cast<char*>(align256(geom)) + (size_t)V * G) : nullptr;
+    B.gr_stride = GR;
     B.iv = image_view(align256(image), p->W, p->H);
     B.iv_stride = I;
     if (binning) {
@@ -207,8 +222,12 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     if (mode != 2 && !out_color) return fail(GSR_ERR_INVALID, "[gsr] out_color is NULL");
     if (mode != 2 && !binning) return fail(GSR_ERR_INVALID, "[gsr] binning arena is NULL");
     Batch B;
-    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, mode == 2 ? nullptr : binning, binning_bytes, B)) return e;
-    if (int e = t_land.ensure()) return e;
+    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, mode == 2 ? nullptr : binning, binning_bytes,
+                           p->need_backward != 0, B))
+        return e;
+    HostLanding* landp = nullptr;
+    if (int e = landing(&landp)) return e;
+    HostLanding& t_land = *landp;
     const Launch L{stream, p->debug};
     const int T = tile_count(p);
     const int gridx = (p->W + TILE_X - 1) / TILE_X;
@@ -241,6 +260,7 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     {
         hipError_t e = V == 1 ? hipMemcpyAsync(t_land.pinned, B.g.counters, 32, hipMemcpyDeviceToHost, L.stream)
                               : hipMemcpy2DAsync(t_land.pinned, 32, B.g.counters, B.g_stride, 32, (size_t)V, hipMemcpyDeviceToHost, L.stream);
+        g_d2h_count++;
         if (e == hipSuccess) e = hipEventRecord(t_land.ev, L.stream);
         if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
     }
@@ -293,7 +313,8 @@ using namespace gsr;
 
 extern "C" {
 
-size_t gsr_geom_bytes(int P) { return geom_view(nullptr, P).bytes + 256; }
+size_t gsr_geom_bytes(int P) { return geom_view(nullptr, P).bytes + grad_rec_bytes(P) + 256; }
+size_t gsr_geom_bytes_inference(int P) { return geom_view(nullptr, P).bytes + 256; }
 size_t gsr_image_bytes(int W, int H) { return image_view(nullptr, W, H).bytes + 256; }
 size_t gsr_binning_bytes(int64_t R) { return bin_view(nullptr, R).bytes + 256; }
 
@@ -349,7 +370,7 @@ int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* g
         return fail(GSR_ERR_INVALID, "[gsr] recolor: bad SH arguments");
     if (!out_color || !p->bg || !binning) return fail(GSR_ERR_INVALID, "[gsr] recolor: NULL pointer");
     Batch B;
-    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, const_cast<void*>(binning), binning_bytes, B)) return e;
+    if (int e = make_batch(p, V, geom, geom_bytes, image, image_bytes, const_cast<void*>(binning), binning_bytes, false, B)) return e;
     const Launch L{(hipStream_t)stream, p->debug};
     const int res = sorted_buffer(tile_count(p));
     {
@@ -360,7 +381,9 @@ int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* g
     }
     {
         ProfScope ps("render_forward", L.stream);
-        if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, false)) return e;
+        // need_backward: the slice-boundary state and the accumulated colour are rewritten for the new colours (and k_recolor
+        // refreshed the SH clamp mask), so a backward afterwards differentiates this render
+        if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0)) return e;
     }
     return GSR_OK;
 }
@@ -379,13 +402,13 @@ int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void*
     if (!binning) return fail(GSR_ERR_INVALID, "[gsr] binning arena is NULL");
     Batch B;
     if (int e = make_batch(p, V, const_cast<void*>(geom), geom_bytes, const_cast<void*>(image), image_bytes,
-                           const_cast<void*>(binning), binning_bytes, B))
+                           const_cast<void*>(binning), binning_bytes, true, B))
         return e;
     const Launch L{(hipStream_t)stream, p->debug};
     const int res = sorted_buffer(tile_count(p));
     {
         ProfScope ps("bwd_items", L.stream);
-        if (int e = launch_bwd_items(L, B, tile_count(p))) return e;
+        if (int e = launch_bwd_items(L, B, tile_count(p), p->P)) return e;
     }
     {
         ProfScope ps("render_backward", L.stream);
@@ -574,6 +597,8 @@ __attribute__((visibility("default"))) int gsr_debug_fwd_times(unsigned long lon
 __attribute__((visibility("default"))) int gsr_debug_bwd_times(unsigned long long* out8, int reset) { return gsr::debug_bwd_times(out8, reset); }
 __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long long* out8, int reset) { return gsr::debug_dup_times(out8, reset); }
 #endif
+
+long long gsr_d2h_count(void) { return gsr::g_d2h_count.load(); }
 
 const char* gsr_last_error(void) { return gsr::g_err; }
 const char* gsr_version(void) { return "gsr-hip 0.2 (gfx950)"; }

@@ -402,9 +402,20 @@ int launch_tile_order(const Launch& L, const Batch& B, int T)
 // state at every chunk boundary), so the longest serial walk in the backward kernel is BWD_CHUNK entries instead of a
 // whole list.  Items are emitted heaviest first with the same bucket scheme as tile_order; a tile's chunk number
 // BWD_MAX_CHUNKS-1 takes everything that is left.  item = tile | chunk << BWD_TILE_BITS.
+// Workgroups with blockIdx.y > 0 are the guard against a REPEATED backward over one forward: when the view's gradient
+// records were already consumed by a backward (CNT_BWD_DIRTY, raised by k_preprocess_backward) they clear them before the
+// render backward accumulates again; normally they read one word and leave.
+constexpr int BWD_CLEAR_BLOCKS = 64;
 __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,
-                                                    uint32_t* __restrict__ count, size_t iv_stride)
+                                                    uint32_t* __restrict__ count, size_t iv_stride, const uint64_t* __restrict__ counters,
+                                                    size_t g_stride, float* __restrict__ grad_rec, size_t gr_stride, size_t gr_bytes)
 {
+    if (blockIdx.y != 0) {
+        if (at_view(counters, g_stride, blockIdx.x)[CNT_BWD_DIRTY] == 0) return;
+        zero_region(reinterpret_cast<char*>(at_view(grad_rec, gr_stride, blockIdx.x)), gr_bytes,
+                    (size_t)(blockIdx.y - 1) * 1024 + threadIdx.x, (size_t)BWD_CLEAR_BLOCKS * 1024);
+        return;
+    }
     need = at_view(need, iv_stride, blockIdx.x);
     items = at_view(items, iv_stride, blockIdx.x);
     count = at_view(count, iv_stride, blockIdx.x);
@@ -451,9 +462,10 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __res
     }
 }
 
-int launch_bwd_items(const Launch& L, const Batch& B, int T)
+int launch_bwd_items(const Launch& L, const Batch& B, int T, int P)
 {
-    hipLaunchKernelGGL(k_bwd_items, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.tile_need, B.iv.bwd_items, B.iv.bwd_count, B.iv_stride);
+    hipLaunchKernelGGL(k_bwd_items, dim3(B.V, 1 + BWD_CLEAR_BLOCKS), dim3(1024), 0, L.stream, T, B.iv.tile_need, B.iv.bwd_items,
+                       B.iv.bwd_count, B.iv_stride, B.g.counters, B.g_stride, B.grad_rec, B.gr_stride, grad_rec_bytes(P));
     return check_launch(L, "bwd_items");
 }
 

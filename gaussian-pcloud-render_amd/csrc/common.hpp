@@ -68,15 +68,19 @@ struct __attribute__((aligned(64))) Splat {
 // grad_rec: [P][GRAD_REC_WORDS] accumulation records of the render backward, one 64-B line per Gaussian:
 //   0 mean2D.x  1 mean2D.y  2 conic.x  3 conic.y  4 conic.w  5..7 colour r g b  8 opacity  (9..15 unused)
 // The nine float atomics a (quadrant, entry) issues land in ONE cache line instead of four arrays' worth
-// (scripts/probe/atomic_probe.hip: 4x the atomic throughput).  Lives in the geometry arena, zeroed by the forward's
-// preprocess kernel (need_backward), so the backward needs no fill pass.
+// (scripts/probe/atomic_probe.hip: 4x the atomic throughput).  The records of the V views follow the V per-view geometry
+// arenas inside the caller's geometry allocation (Batch::grad_rec; only calls with need_backward carve and need them),
+// zeroed by the forward's preprocess kernel, so the backward needs no fill pass.
 constexpr int GRAD_REC_WORDS = 16;
+inline size_t grad_rec_bytes(int P) { return ((size_t)(P > 0 ? P : 1) * GRAD_REC_WORDS * sizeof(float) + 255) / 256 * 256; }
 
 // counters[] slots (geometry arena, per view)
 constexpr int CNT_NUM_RENDERED = 0;  // true number of (tile, Gaussian) pairs, even when it exceeds the arena capacity
 constexpr int CNT_TRAP = 1;          // prefiltered = 1 but a Gaussian was culled
 constexpr int CNT_STALL = 2;         // the pair emission gave up waiting for a preceding workgroup's count (never expected;
                                      // cleared by k_preprocess, checked by the host: every spin in the library is bounded)
+constexpr int CNT_BWD_DIRTY = 3;     // a backward has accumulated into this view's gradient records since the forward cleared
+                                     // them: the next backward on the same arenas clears them first (k_bwd_items)
 
 // ---- arena views (device pointers carved out of the caller's opaque buffers) -------------------
 struct GeomView {
@@ -87,7 +91,6 @@ struct GeomView {
     uint32_t* dval[2];        // [P] Gaussian ids, ping-pong; after 4 passes dval[0] = ids in depth order
     uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts (depth sort)
     uint32_t* totals;         // [RADIX]
-    float* grad_rec;          // [P][GRAD_REC_WORDS]
     uint64_t* dup_status;     // [ceil(P / DUP_THREADS) + 1] pair count + 1 of each emission workgroup, then the ticket counter
     uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
     char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
@@ -153,7 +156,6 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.dval[1], p);
     carve(cur, g.hist, RADIX * nblk);
     carve(cur, g.totals, (size_t)RADIX);
-    carve(cur, g.grad_rec, p * GRAD_REC_WORDS);
     g.zero_begin = cur;
     carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS) + 1);   // + the ticket counter
     g.zero_bytes = (size_t)(cur - g.zero_begin);
@@ -240,6 +242,8 @@ struct Batch {
     size_t iv_stride;
     BinView b;          // carved by capacity (b.cap); b.key[0] == nullptr when no binning arena was given
     size_t b_stride;
+    float* grad_rec;    // view 0's [P][GRAD_REC_WORDS] gradient records, behind the V geometry arenas; NULL without need_backward
+    size_t gr_stride;
 };
 
 int check_launch(const Launch& L, const char* what);  // api.hip
@@ -269,7 +273,7 @@ inline bool tile_keys16(int T) { return T <= 65536; }
 int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16);
 int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16);
 int launch_tile_order(const Launch& L, const Batch& B, int T);
-int launch_bwd_items(const Launch& L, const Batch& B, int T);
+int launch_bwd_items(const Launch& L, const Batch& B, int T, int P);
 // render_fwd.hip / render_bwd.hip
 // point_list: view 0's sorted ids (binning arena); with_ckpt: record the chunk-boundary state for the backward pass
 // Extra channels composited by the forward render with the alphas of the colour pass (4 or 8 per call).

@@ -86,7 +86,7 @@ struct PreArgs {
     float* grad_rec;
     uint64_t* counters;
     char* g_zero;                         // per-frame cleared regions of the geometry / image arenas
-    size_t g_zero_bytes, g_stride;
+    size_t g_zero_bytes, g_stride, gr_stride;
     char* iv_zero;
     size_t iv_zero_bytes, iv_stride;
     int* radii;                           // [V][P]
@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     {
         const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
         for (int vw = v_first; vw < v_last; vw++) {
-            if (gtid == 0) at_view(a.counters, a.g_stride, vw)[CNT_STALL] = 0;
+            if (gtid == 0) {
+                at_view(a.counters, a.g_stride, vw)[CNT_STALL] = 0;
+                at_view(a.counters, a.g_stride, vw)[CNT_BWD_DIRTY] = 0;   // the gradient records are cleared below
+            }
             zero_region(a.g_zero + a.g_stride * vw, a.g_zero_bytes, gtid, nthr);
             zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
         }
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         if (a.need_backward) {
             at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
             // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
-            float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.g_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
+            float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.gr_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
         }
@@ -240,7 +243,7 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.scales = p.scales; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
     a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
     a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped;
-    a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters; a.grad_rec = g.grad_rec;
+    a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters; a.grad_rec = B.grad_rec; a.gr_stride = B.gr_stride;
     a.g_zero = g.zero_begin; a.g_zero_bytes = g.zero_bytes; a.g_stride = B.g_stride;
     a.iv_zero = B.iv.zero_begin; a.iv_zero_bytes = B.iv.zero_bytes; a.iv_stride = B.iv_stride;
     const int blocks = (p.P + 255) / 256;
@@ -269,7 +272,8 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
 __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const float* __restrict__ means3D,
                                                  const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                                                  const float* __restrict__ campos, const uint32_t* __restrict__ tiles_touched,
-                                                 Splat* __restrict__ splat, size_t g_stride, size_t colors_view_stride)
+                                                 Splat* __restrict__ splat, uint8_t* __restrict__ clamped, size_t g_stride,
+                                                 size_t colors_view_stride)
 {
     const uint32_t vw = blockIdx.y;
     if (colors_precomp) colors_precomp += colors_view_stride * vw;
@@ -279,10 +283,10 @@ __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const floa
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || tiles_touched[idx] == 0) return;
     V3 rgb;
+    uint32_t cmask = 0;
     if (colors_precomp) {
         rgb = v3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
     } else {
-        uint32_t cmask;
         const V3 pos = v3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         rgb = sh_to_rgb(D, pos, v3(campos[0], campos[1], campos[2]), shs + (size_t)idx * M * 3, &cmask);
     }
@@ -290,12 +294,14 @@ __global__ __launch_bounds__(256) void k_recolor(int P, int D, int M, const floa
     rec[6] = rgb.x;  // q1.z
     rec[7] = rgb.y;  // q1.w
     rec[8] = rgb.z;  // q2.x
+    if (clamped) at_view(clamped, g_stride, vw)[idx] = (uint8_t)cmask;   // need_backward: the SH backward reads the new mask
 }
 
 int launch_recolor(const Launch& L, const gsr_params& p, const Batch& B, size_t colors_view_stride)
 {
     hipLaunchKernelGGL(k_recolor, dim3((p.P + 255) / 256, B.V), dim3(256), 0, L.stream, p.P, p.D, p.M, p.means3D, p.shs,
-                       p.colors_precomp, p.campos, B.g.tiles_touched, B.g.splat, B.g_stride, colors_view_stride);
+                       p.colors_precomp, p.campos, B.g.tiles_touched, B.g.splat, p.need_backward ? B.g.clamped : nullptr, B.g_stride,
+                       colors_view_stride);
     return check_launch(L, "recolor");
 }
 

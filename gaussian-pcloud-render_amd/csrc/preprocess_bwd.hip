@@ -63,7 +63,8 @@ struct PreBwdArgs {
     const int* radii;                    // [V][P]
     const uint8_t* clamped;
     const float* grad_rec;               // [P][GRAD_REC_WORDS] per view, see common.hpp
-    size_t g_stride;
+    size_t g_stride, gr_stride;
+    uint64_t* counters;                  // per view (CNT_*): CNT_BWD_DIRTY is raised once the records have been consumed
     float *dL_dmean2D, *dL_dopacity, *dL_dcolor;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
@@ -154,6 +155,11 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     const bool active = blockIdx.x * 256 + threadIdx.x < (unsigned)a.P;
     const int idx = active ? (int)(blockIdx.x * 256 + threadIdx.x) : a.P - 1;   // idle lanes of the last block shadow a real one
 
+    // The records now hold this backward's sums.  A further backward over the same forward (retain_graph, a second
+    // gsr_backward call) must not add to them: it finds the flag and clears the records first (k_bwd_items), where the
+    // reference zero-fills its accumulators on every call (rasterize_points.cu:151-159).
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)a.V) at_view(a.counters, a.g_stride, threadIdx.x)[CNT_BWD_DIRTY] = 1;
+
     // sums over the views of the batch
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
     V3 gcol = v3(0, 0, 0), gmean = v3(0, 0, 0);
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 
     for (int vw = 0; vw < a.V; vw++) {
         // the render-level sums of this Gaussian in this view: one 64-B record (zeros when nothing was accumulated)
-        const float* recp = at_view(a.grad_rec, a.g_stride, (uint32_t)vw) + (size_t)idx * GRAD_REC_WORDS;
+        const float* recp = at_view(a.grad_rec, a.gr_stride, (uint32_t)vw) + (size_t)idx * GRAD_REC_WORDS;
         const float4 rec0 = *reinterpret_cast<const float4*>(recp);
         const float4 rec1 = *reinterpret_cast<const float4*>(recp + 4);
         const float rec8 = recp[8];
@@ -339,7 +345,7 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch
     a.means3D = p.means3D; a.shs = p.shs; a.scales = p.scales; a.rotations = p.rotations;
     a.cov3D_precomp = p.cov3D_precomp; a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
     a.radii = radii; a.clamped = B.g.clamped;
-    a.grad_rec = B.g.grad_rec; a.g_stride = B.g_stride;
+    a.grad_rec = B.grad_rec; a.g_stride = B.g_stride; a.gr_stride = B.gr_stride; a.counters = B.g.counters;
     a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
     const dim3 grid((p.P + 255) / 256), block(256);

@@ -252,7 +252,7 @@ struct RenderBwdArgs {
     const float* dL_dpix;
     float* grad_rec;     // [P][GRAD_REC_WORDS] accumulation records (common.hpp)
     uint32_t V;
-    size_t g_stride, b_stride, iv_stride;
+    size_t g_stride, b_stride, iv_stride, gr_stride;
 };
 
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     a.ckpt = at_view(a.ckpt, a.b_stride, view);
     a.point_list = at_view(a.point_list, a.b_stride, view);
     a.splat = at_view(a.splat, a.g_stride, view);
-    a.grad_rec = at_view(a.grad_rec, a.g_stride, view);
+    a.grad_rec = at_view(a.grad_rec, a.gr_stride, view);
     a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
     __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
@@ -600,7 +600,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     a.final_T = B.iv.final_T;
     a.n_contrib = B.iv.n_contrib;
     a.dL_dpix = dL_dpix;
-    a.grad_rec = B.g.grad_rec;
+    a.grad_rec = B.grad_rec; a.gr_stride = B.gr_stride;
     a.num_tiles = a.gridx * gridy;
     a.V = (uint32_t)B.V;
     a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;

@@ -196,18 +196,54 @@ class GaussianRasterizer(nn.Module):
 # points below take the list of per-view settings instead and hand the whole batch to the C ABI's gsr_forward_batch /
 # gsr_backward_batch: one preprocess grid over V x P, one render grid over all views' tiles, and gradients summed over the
 # views on the device -- the same numbers as V separate calls whose gradients autograd adds up.
+# The per-view matrices of a settings list are packed ONCE into [V,4,4] / [V,4,4] / [V,3] device blocks and remembered:
+# a training loop hands over the same settings objects every iteration, and rebuilding the blocks (36 tiny copies + 3 stacks)
+# or comparing backgrounds through host memory (a blocking device->host copy per view, which drains the stream) would put
+# the host back on the critical path of every call.  Steady state: no torch kernel, no copy, no synchronisation.
+_VIEW_BLOCKS = {}          # key -> (view, proj, cam, the source tensors kept alive so that their addresses cannot be reused)
+_VIEW_BLOCKS_MAX = 32
+_BG_SAME = {}              # (ptr, version, ptr, version) -> the two background tensors hold the same three values
+
+
+def _tkey(t):
+    return (t.data_ptr(), t._version, t.device.type, t.device.index)
+
+
+def _same_background(a, b):
+    if a is b or (a.data_ptr() == b.data_ptr() and a.device == b.device and a.numel() == b.numel()):
+        return True
+    k = _tkey(a) + _tkey(b)
+    r = _BG_SAME.get(k)
+    if r is None:
+        if len(_BG_SAME) >= 256:
+            _BG_SAME.clear()
+        r = (torch.equal(a.detach().cpu(), b.detach().cpu()), a, b)     # one host comparison per pair of tensors, ever
+        _BG_SAME[k] = r
+    return r[0]
+
+
 def _stack_views(settings_list, device):
     s0 = settings_list[0]
     for s in settings_list[1:]:
         if (s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.scale_modifier, s.sh_degree, s.prefiltered) != (
                 s0.image_height, s0.image_width, s0.tanfovx, s0.tanfovy, s0.scale_modifier, s0.sh_degree, s0.prefiltered) or \
-                not torch.equal(s.bg.cpu(), s0.bg.cpu()):
+                not _same_background(s.bg, s0.bg):
             raise Exception("rasterize_views: the views of a batch must share image size, tan(fov), background, scale "
                             "modifier, SH degree and the prefiltered flag")
-    view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
-    proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
-    cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
-    return view, proj, cam
+    key = (device.type, device.index) + tuple(k for s in settings_list for t in (s.viewmatrix, s.projmatrix, s.campos)
+                                               for k in _tkey(t))
+    hit = _VIEW_BLOCKS.get(key)
+    if hit is None:
+        view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+        proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+        cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
+        # other host threads may use the blocks on other streams right away: finish the copies once, here
+        torch.cuda.current_stream(device).synchronize()
+        if len(_VIEW_BLOCKS) >= _VIEW_BLOCKS_MAX:
+            _VIEW_BLOCKS.pop(next(iter(_VIEW_BLOCKS)))
+        hit = (view, proj, cam, [(s.viewmatrix, s.projmatrix, s.campos) for s in settings_list])
+        _VIEW_BLOCKS[key] = hit
+    return hit[0], hit[1], hit[2]
 
 
 class _RasterizeGaussiansViews(torch.autograd.Function):

@@ -30,9 +30,9 @@ class GsrParams(C.Structure):
 
 
 # every symbol include/gsr.h declares (tests check the library exports all of them)
-SYMBOLS = ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
+SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
-           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels")
+           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count")
 
 GSR_RETRY = 1
 
@@ -48,6 +48,8 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.gsr_geom_bytes.restype = C.c_size_t
     lib.gsr_geom_bytes.argtypes = [C.c_int]
+    lib.gsr_geom_bytes_inference.restype = C.c_size_t
+    lib.gsr_geom_bytes_inference.argtypes = [C.c_int]
     lib.gsr_image_bytes.restype = C.c_size_t
     lib.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
     lib.gsr_binning_bytes.restype = C.c_size_t
@@ -83,6 +85,8 @@ def _load():
     lib.gsr_get_profile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.gsr_selftest.restype = C.c_int
     lib.gsr_selftest.argtypes = [_fp]
+    lib.gsr_d2h_count.restype = C.c_longlong
+    lib.gsr_d2h_count.argtypes = []
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
     return lib
@@ -210,7 +214,8 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                           viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, prefiltered, debug,
                           need_backward)
-        geom = torch.empty((V * lib.gsr_geom_bytes(P),), **byte)
+        # the 64-B per-Gaussian gradient records are only carved for calls a backward may follow
+        geom = torch.empty((V * (lib.gsr_geom_bytes(P) if need_backward else lib.gsr_geom_bytes_inference(P)),), **byte)
         img = torch.empty((V * lib.gsr_image_bytes(W, H),), **byte)
         counts = (C.c_int64 * V)()
         if capacity is None:
@@ -381,7 +386,7 @@ def query(name, P, W, H, R, geom, binning, img, view=0, n_views=1):
     p = GsrParams()
     p.P, p.W, p.H = P, W, H
     # view v's arenas start v strides into the allocations (include/gsr.h: V identically laid out single-view arenas)
-    g_stride, i_stride = lib.gsr_geom_bytes(P) - 256, lib.gsr_image_bytes(W, H) - 256
+    g_stride, i_stride = lib.gsr_geom_bytes_inference(P) - 256, lib.gsr_image_bytes(W, H) - 256
     b_stride = ((binning.numel() - 256) // n_views) // 256 * 256 if binning.numel() else 0
     if geom.data_ptr() % 256 or img.data_ptr() % 256 or (binning.numel() and binning.data_ptr() % 256):
         raise RuntimeError("query: arena base pointers are expected to be 256-byte aligned")

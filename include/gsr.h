@@ -88,6 +88,10 @@ typedef struct gsr_params {
 /* Scratch arena sizes in bytes for ONE view (256-B aligned sub-arrays inside); a batch of V views needs V times as much.
  * gsr_binning_bytes(n) is an arena that holds n pairs per view: the library derives the capacity from the arena's size. */
 size_t gsr_geom_bytes(int P);
+/* The geometry arena of a call with need_backward = 0 (inference): without the 64-B per-Gaussian gradient records that only
+ * the backward accumulates into (they follow the V per-view arenas inside the allocation, so the layout of everything else
+ * does not depend on the flag).  A forward with need_backward = 1 and every backward need V * gsr_geom_bytes(P). */
+size_t gsr_geom_bytes_inference(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int64_t num_rendered);
 
@@ -132,7 +136,10 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
  * ranges: p->colors_precomp (verbatim; [P,3] shared by the views, or [V,P,3] with colors_per_view != 0 -- the reference's
  * normal pass flips the normals' sign per view) or p->shs (evaluated like the forward does); only P, D, M, W, H, bg, means3D,
  * shs / colors_precomp, campos of *p are read.  The result is bit-identical to a full forward with those colours.  The
- * arenas stay valid for further recolor calls; a backward afterwards differentiates the LAST colours rendered. */
+ * arenas stay valid for further recolor calls.  With p->need_backward = 1 (and arenas of a need_backward forward) the
+ * saves the backward reads are rewritten too (per-pixel state at the list-slice boundaries, accumulated colour, SH clamp
+ * mask), so a backward afterwards -- called with the SAME colour inputs -- differentiates the LAST colours rendered; with
+ * need_backward = 0 a backward after the recolor is not supported. */
 int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* geom, size_t geom_bytes, const void* binning,
                         size_t binning_bytes, void* image, size_t image_bytes, float* out_color, gsr_stream_t stream);
 
@@ -141,7 +148,8 @@ int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* g
  * cloud).  Every output is written for every Gaussian (zeros where it is invisible; all M rows of dL_dsh), so nothing has
  * to be cleared by the caller -- the reference zero-fills nine tensors per call (rasterize_points.cu:151-159) -- except
  * dL_dscale / dL_drot, which are not touched when cov3D_precomp is given.  The reference's internal dL_dconic accumulator
- * lives in the geometry arena.  Valid after a forward with need_backward = 1 on the same arenas.
+ * lives in the geometry arena.  Valid after a forward with need_backward = 1 on the same arenas, any number of times: every
+ * call returns the gradients of ITS dL_dpix (a repeated call first clears what the previous one accumulated).
  * shapes: radii[V,P] dL_dmean2D[P,3] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3]
  * dL_dscale[P,3] dL_drot[P,4]. */
 int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void* geom, size_t geom_bytes, const void* binning,
@@ -187,6 +195,11 @@ int gsr_get_profile(const char** names, float* ms, int cap);
 /* Device self-test of internal primitives (wave reduction of the backward pass, stable radix sort vs std::stable_sort).
  * Allocates its own small buffers; not part of the hot path.  0 = pass. */
 int gsr_selftest(gsr_stream_t stream);
+
+/* Number of device->host read-backs the library has issued in this process: exactly one per forward call (the 32-byte
+ * per-view counter block: num_rendered, trap and stall flags), none per backward.  For tests that guard the call path
+ * against host stalls. */
+long long gsr_d2h_count(void);
 
 const char* gsr_last_error(void);
 const char* gsr_version(void);

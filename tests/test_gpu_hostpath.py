@@ -1,0 +1,161 @@
+"""GPU tests (-m gpu) of the HOST side of the call path: nothing between the caller and the kernels may wait for the device
+or copy to the host, except the one 32-byte counter read-back per forward call that the C ABI documents (include/gsr.h).
+
+  * GaussianRasterizer.forward / backward and rasterize_views under torch's sync-debug mode "error" (any torch-level
+    synchronising op -- .cpu(), .item(), torch.equal on device tensors -- raises), with the library's own read-back counter
+    advancing by exactly one per forward call and not at all per backward;
+  * the packed per-view blocks of rasterize_views are built once per settings list, not per call;
+  * a repeated backward over one forward (retain_graph=True; two gsr_backward_batch calls on the same arenas) returns the
+    same gradients each time (the reference zero-fills its accumulators per call, rasterize_points.cu:151-159).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _setup(dev, n_views=3, P=12000, W=208, H=176):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    from pcrender import camera, synth
+    cloud = synth.make_cloud("synth-THuman-256", seed=0, P=P)
+    g = synth.make_gaussians(cloud, profile="training", seed=1)
+    views = camera.circle_views(12, fov_deg=45.0, width_px=W, height_px=H)[:n_views]
+    bg = torch.ones(3, device=dev)
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=v["tanfovx"], tanfovy=v["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=v["viewmatrix"].to(dev), projmatrix=v["projmatrix"].to(dev), sh_degree=g["sh_degree"],
+        campos=v["campos"].to(dev), prefiltered=False, debug=False) for v in views]
+
+    def leaves():
+        m3 = _t(g["means3D"], dev).requires_grad_(True)
+        return dict(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), shs=_t(g["shs"], dev).requires_grad_(True),
+                    opacities=_t(g["opacities"], dev).requires_grad_(True), scales=_t(g["scales"], dev).requires_grad_(True),
+                    rotations=_t(g["rotations"], dev).requires_grad_(True))
+    G = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
+    return settings, leaves, G
+
+
+class _no_sync:
+    """torch raises on every synchronising torch call inside the block"""
+    def __enter__(self):
+        self.old = torch.cuda.get_sync_debug_mode()
+        torch.cuda.set_sync_debug_mode("error")
+
+    def __exit__(self, *a):
+        torch.cuda.set_sync_debug_mode(self.old)
+
+
+def test_per_view_call_makes_one_readback_and_no_torch_sync(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer, _native as N
+    dev = gpu_device
+    settings, leaves, G = _setup(dev)
+    L = leaves()
+    r = GaussianRasterizer(settings[1])
+    for _ in range(2):      # first call of a configuration counts pairs synchronously (stage 1 / stage 2); then steady state
+        img, _ = r(**L)
+        (img * G).sum().backward()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        c0 = N.lib.gsr_d2h_count()
+        with _no_sync():
+            img, radii = r(**L)
+            c1 = N.lib.gsr_d2h_count()
+            (img * G).sum().backward()
+            c2 = N.lib.gsr_d2h_count()
+        assert c1 - c0 == 1, "forward: %d device->host read-backs (exactly one expected)" % (c1 - c0)
+        assert c2 - c1 == 0, "backward must not read anything back"
+    torch.cuda.synchronize()
+    assert torch.isfinite(L["means3D"].grad).all()
+
+
+def test_rasterize_views_makes_one_readback_and_no_torch_sync(gpu_device):
+    from diff_gaussian_rasterization import _native as N, rasterize_views
+    import diff_gaussian_rasterization as d
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=4)
+    L = leaves()
+
+    def call():
+        imgs, radii = rasterize_views(L["means3D"], L["means2D"], L["opacities"], settings, shs=L["shs"], scales=L["scales"],
+                                      rotations=L["rotations"])
+        (imgs * G).sum().backward()
+        return imgs
+
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    blocks = len(d._VIEW_BLOCKS)
+    for rep in range(3):
+        c0 = N.lib.gsr_d2h_count()
+        with _no_sync():
+            call()
+        assert N.lib.gsr_d2h_count() - c0 == 1
+    # a NEW list object of the same settings reuses the packed blocks too
+    with _no_sync():
+        imgs2, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], list(settings), shs=L["shs"], scales=L["scales"],
+                                   rotations=L["rotations"])
+    assert len(d._VIEW_BLOCKS) == blocks
+    torch.cuda.synchronize()
+    # in-place change of a view matrix is seen (version counter in the key), not served from the cache
+    ref = imgs2.detach().clone()
+    settings[2].viewmatrix.mul_(1.0)
+    imgs3, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], settings, shs=L["shs"], scales=L["scales"],
+                               rotations=L["rotations"])
+    assert len(d._VIEW_BLOCKS) == blocks + 1 and torch.equal(imgs3, ref)
+    # backgrounds that are different tensors with equal values are accepted, unequal ones rejected
+    s_alt = [s._replace(bg=torch.ones(3, device=dev)) if i == 1 else s for i, s in enumerate(settings)]
+    rasterize_views(L["means3D"], L["means2D"], L["opacities"], s_alt, shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+    s_bad = [s._replace(bg=torch.zeros(3, device=dev)) if i == 1 else s for i, s in enumerate(settings)]
+    with pytest.raises(Exception, match="must share image size"):
+        rasterize_views(L["means3D"], L["means2D"], L["opacities"], s_bad, shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+
+
+def test_repeated_backward_returns_the_same_gradients(gpu_device):
+    from diff_gaussian_rasterization import GaussianRasterizer, rasterize_views
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=3)
+    # per-view call, retain_graph
+    L = leaves()
+    img, _ = GaussianRasterizer(settings[1])(**L)
+    loss = (img * G).sum()
+    names = list(L)
+    g1 = torch.autograd.grad(loss, [L[k] for k in names], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [L[k] for k in names], retain_graph=True)
+    g3 = torch.autograd.grad(2.0 * loss, [L[k] for k in names])
+    for k, a, b, c in zip(names, g1, g2, g3):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-5 * scale, "second backward differs from the first (%s)" % k
+        assert float((c - 2 * a).abs().max()) <= 1e-5 * 2 * scale, "third backward (2 x loss) is not twice the first (%s)" % k
+    # view batch
+    L = leaves()
+    imgs, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], settings, shs=L["shs"], scales=L["scales"],
+                              rotations=L["rotations"])
+    loss = (imgs * G).sum()
+    g1 = torch.autograd.grad(loss, [L[k] for k in names], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [L[k] for k in names])
+    for k, a, b in zip(names, g1, g2):
+        assert float((a - b).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-30), "batch: second backward differs (%s)" % k
+
+
+def test_inference_geometry_arena_is_smaller_and_enough(gpu_device):
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=3)
+    L = leaves()
+    P = L["means3D"].shape[0]
+    assert N.lib.gsr_geom_bytes(P) - N.lib.gsr_geom_bytes_inference(P) >= 64 * P
+    e = torch.empty(0)
+    vm = torch.stack([s.viewmatrix for s in settings]); pm = torch.stack([s.projmatrix for s in settings])
+    cp = torch.stack([s.campos.reshape(3) for s in settings])
+    s0 = settings[0]
+    args = (s0.bg, L["means3D"].detach(), e, L["opacities"].detach(), L["scales"].detach(), L["rotations"].detach(), 1.0, e, vm, pm,
+            s0.tanfovx, s0.tanfovy, s0.image_height, s0.image_width, L["shs"].detach(), s0.sh_degree, cp, False, False)
+    c_inf, col_inf, rad_inf, geom_inf, *_ = N.rasterize_gaussians_batch(*args, need_backward=False)
+    c_bwd, col_bwd, rad_bwd, geom_bwd, *_ = N.rasterize_gaussians_batch(*args, need_backward=True)
+    assert geom_inf.numel() == 3 * N.lib.gsr_geom_bytes_inference(P) and geom_bwd.numel() == 3 * N.lib.gsr_geom_bytes(P)
+    assert c_inf == c_bwd and torch.equal(col_inf, col_bwd) and torch.equal(rad_inf, rad_bwd)
