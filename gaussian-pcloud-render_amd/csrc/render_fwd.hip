@@ -26,6 +26,8 @@
 // k_render_forward<NX>, NX = 4 or 8: the same walk also composites NX extra per-Gaussian channels with the colour's alphas
 // (gsr_forward_batch_channels: the reference's callers render world xyz, a hit map and normals as three more full passes,
 // simple_raw_render.py:410-524).  The extra values ride in the pair records next to the colour; NX = 0 is the plain kernel.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -178,24 +180,18 @@ int debug_fwd_times(unsigned long long* out8, int reset)
 }
 #endif
 
-template <int NX>
-__global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
+// XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant workgroups of
+// one tile are b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records are fetched into
+// that L2 once instead of four times.
+// Batches: groups of 32 workgroups (8 tiles x 4 quadrants) are dealt to the views round-robin, so the heaviest tiles of
+// EVERY view are dispatched first and the batch has one tail instead of one per view.
+// Returns false when the workgroup has no tile; otherwise `a` points at the view's arrays.
+__device__ __forceinline__ bool locate_work(RenderArgs& a, uint32_t& view, uint32_t& tile, uint32_t& q)
 {
-#ifdef GSR_STATS
-    FW_T(tw0);
-    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
-#endif
-    static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
-    constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
-    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
-    // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
-    // are fetched into that L2 once instead of four times.
-    // Batches: groups of 32 workgroups (8 tiles x 4 quadrants) are dealt to the views round-robin, so the heaviest tiles of
-    // EVERY view are dispatched first and the batch has one tail instead of one per view.
     const uint32_t group = blockIdx.x >> 5;
-    const uint32_t view = group % a.V;
+    view = group % a.V;
     const uint32_t order_slot = (group / a.V) * 8u + (blockIdx.x & 7u);
-    if (order_slot >= (uint32_t)a.num_tiles) return;
+    if (order_slot >= (uint32_t)a.num_tiles) return false;
     a.ranges = at_view(a.ranges, a.iv_stride, view);
     a.tile_order = at_view(a.tile_order, a.iv_stride, view);
     a.final_T = at_view(a.final_T, a.iv_stride, view);
@@ -206,9 +202,23 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
     a.splat = at_view(a.splat, a.g_stride, view);
     a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
-    const uint32_t tile = a.tile_order[order_slot];
-    const uint32_t q = (blockIdx.x >> 3) & 3u;
-    const uint32_t lane = threadIdx.x;
+    tile = a.tile_order[order_slot];
+    q = (blockIdx.x >> 3) & 3u;
+    return true;
+}
+
+// One wave64 walks the list of `tile` for the 8x8 quadrant q on its own (header comment).  `stage`: 33 * (PAIR_WORDS + 2 NX)
+// floats of LDS that belong to the calling wave.
+template <int NX>
+__device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_t view, const uint32_t tile, const uint32_t q,
+                                              const uint32_t lane, float* __restrict__ stage)
+{
+#ifdef GSR_STATS
+    FW_T(tw0);
+    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
+#endif
+    static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
+    constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
     const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
     const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
@@ -218,8 +228,6 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     // rectangle of the pixels that are still live (not outside the image, not terminated): the footprint test only has to
     // keep entries that can reach one of those
     float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 7.f;
-
-    __shared__ __attribute__((aligned(16))) float stage[33 * PW];   // 32 pairs + one that may be read, never used
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -501,6 +509,475 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     }
 }
 
+template <int NX>
+__global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float stage[33 * (PAIR_WORDS + 2 * NX)];   // 32 pairs + one that may be read, never used
+    uint32_t view, tile, q;
+    if (!locate_work(a, view, tile, q)) return;
+    quadrant_walk<NX>(a, view, tile, q, threadIdx.x, stage);
+}
+
+
+// ---- cooperative quadrants: the drop-in (one view per call) forward --------------------------------------------------
+// A single view's launch is over when its deepest list walks are: a quadrant wave walks its list serially, at the
+// cadence of a lone wave (one instruction per ~5.5 cycles), and ~70 instructions per entry pair are spent on what does NOT
+// depend on the walk -- the gather, the footprint test, power / exp / alpha of every entry for every pixel.  Only the blend
+// is sequential: T *= (1 - alpha), C += c * alpha * T, the stop test.  For lists of COOP_MIN_LIST entries or more the work
+// is therefore split over the four waves of a workgroup that share ONE quadrant:
+//   wave 1 (stager): gathers 64 list entries per round, runs the footprint test against the pixels still live and appends
+//     the survivors, compacted in pairs, to a ring of records in LDS; cuts the stream into BATCHES of COOP_BATCH pairs;
+//   waves 1..3 (producers): evaluate alpha of a batch's pairs for all 64 pixels -- the packed evaluation of quadrant_walk,
+//     term for term -- and write (alpha or 0) rows into an LDS buffer;
+//   wave 0 (consumer): walks the rows of the previous batch in list order and does nothing but the reference's sequential
+//     part (CR/forward.cu:328-365): T * (1 - alpha), the stop test, C += c * alpha * T, last contributor.
+// One barrier per batch; alpha rows are double buffered, so batch i + 1 is being staged and batch i evaluated while the
+// consumer blends batch i - 1.  The values blended and their order are those of quadrant_walk, hence of the reference:
+// out_color, final_T, n_contrib, tile_need and the slice-boundary state are bit-identical to the single-wave walk (every
+// forward parity test runs through this kernel: V <= coop_max_views()).  The footprint test sees the live pixels two or
+// three batches late, which keeps it conservative (a terminated pixel's alphas are multiplied by 0 in the consumer).
+// Tiles with shorter lists are walked by the four waves of the q == 0 workgroup, one quadrant each, with quadrant_walk.
+#ifdef GSR_STATS
+// instrumentation build only: per-wave time split of the cooperative kernel's LAST launch (10-ns ticks), one record per wave:
+// 0 life, 1 in barriers, 2 role work A (consumer: blending; stager: forming batches; producer: evaluating), 3 role work B (stager:
+// waiting for gathered records), 4 role work C (stager: evaluating), 5 iterations, 6 pairs / rounds, 7 role + 1
+constexpr int CO_REC = 1 << 18;
+__device__ unsigned g_coop_rec[CO_REC][8];
+#define CO_T(var) const unsigned long long var = wall_clock64()
+#define CO_ADD(acc, a_, b_) acc += (b_) - (a_)
+int debug_coop_times(unsigned long long* out32, int reset)
+{
+    static unsigned host[CO_REC][8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_coop_rec), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 32; i++) out32[i] = 0;
+    for (int r = 0; r < CO_REC; r++) {
+        const unsigned role = host[r][7];
+        if (role == 0 || role > 3) continue;
+        unsigned long long* o = out32 + 8 * (role - 1);
+        for (int i = 0; i < 7; i++) o[i] += host[r][i];
+        o[7]++;
+        if (host[r][0] > out32[24 + role - 1]) out32[24 + role - 1] = host[r][0];   // the longest-lived wave of the role
+    }
+    if (reset) {
+        for (int r = 0; r < CO_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_rec), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define CO_BARRIER() do { CO_T(tb0_); __syncthreads(); CO_T(tb1_); CO_ADD(tw_bar, tb0_, tb1_); } while (0)
+#define CO_DECL() CO_T(tw0); unsigned long long tw_bar = 0, tw_a = 0, tw_b = 0, tw_c = 0, n_it = 0, n_x = 0
+#define CO_STORE(role) do { if (lane == 0) { const unsigned ri = blockIdx.x * 4u + (role); if (ri < (unsigned)CO_REC) { CO_T(tw1); unsigned* r_ = g_coop_rec[ri]; \
+    r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_bar; r_[2] = (unsigned)tw_a; r_[3] = (unsigned)tw_b; r_[4] = (unsigned)tw_c; \
+    r_[5] = (unsigned)n_it; r_[6] = (unsigned)n_x; r_[7] = (role) >= 2u ? 3u : (role) + 1u; } } } while (0)
+#else
+#define CO_BARRIER() __syncthreads()
+#define CO_DECL() do { } while (0)
+#define CO_STORE(role) do { } while (0)
+#endif
+
+constexpr int COOP_BATCH = 16;        // pairs per batch
+constexpr int COOP_RING = 96;         // pairs: batch i - 1 (consumer) + batch i (producers) + batch i + 1 and up to 47 more staged
+#ifndef GSR_COOP_MIN_LIST
+#define GSR_COOP_MIN_LIST 768
+#endif
+constexpr int COOP_MIN_LIST = GSR_COOP_MIN_LIST;
+
+struct CoopShared {
+    float alpha[2][COOP_BATCH][64][2];    // (alpha or 0) of the pair's two entries, per pixel                      16 KB
+    float prec[COOP_RING][12];            // producers' record of a pair: x0 x1 y0 y1 | A0 A1 B0 B1 | C0 C1 o0 o1
+    float crec[COOP_RING][8];             // consumer's record of a pair: r0 g0 r1 g1 | b0 b1 | pos0 pos1
+    uint32_t desc[4][4];                  // batch i in slot i & 3: first ring pair, pairs, last batch, slice boundaries (first | count << 16)
+    uint64_t live[2];                     // pixels not yet terminated, as of the end of iteration i (slot i & 1)
+    uint32_t finished[2];                 // the consumer is done: every pixel terminated, or the last batch has been blended
+};
+
+union CoopLds {
+    CoopShared co;
+    float light[4][33 * PAIR_WORDS];      // quadrant_walk staging of the four waves (short lists)
+};
+
+// alpha rows of pairs [p0, p1) of the batch that starts at ring pair `first`
+__device__ __forceinline__ void coop_eval_pairs(CoopShared& sh, const int buf, const uint32_t first, const int p0, const int p1,
+                                                const uint32_t lane, const float pixf_x, const float pixf_y)
+{
+    if (p0 >= p1) return;
+    uint32_t ring = first + (uint32_t)p0;
+    if (ring >= (uint32_t)COOP_RING) ring -= COOP_RING;
+    const float* r = &sh.prec[ring][0];
+    f32x4 xy = *(const f32x4*)(r + 0), ab = *(const f32x4*)(r + 4), co = *(const f32x4*)(r + 8);
+    for (int pr = p0; pr < p1; pr++) {
+        // pair p + 1 is read from LDS while pair p is evaluated (one past the last is a valid ring slot)
+        if (++ring == (uint32_t)COOP_RING) ring = 0;
+        const float* nx = &sh.prec[ring][0];
+        const f32x4 xy2 = *(const f32x4*)(nx + 0), ab2 = *(const f32x4*)(nx + 4), co2 = *(const f32x4*)(nx + 8);
+        const f32x2 X = {xy.x, xy.y}, Y = {xy.z, xy.w}, A2 = {ab.x, ab.y}, B2 = {ab.z, ab.w};
+        const f32x2 C2p = {co.x, co.y}, O2 = {co.z, co.w};
+        const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
+        const f32x2 power = -0.5f * (A2 * dx * dx + C2p * dy * dy) - B2 * dx * dy;
+        const f32x2 al = O2 * exp_nonpos2(power);
+        const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+        const bool cnt0 = !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
+        const bool cnt1 = !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
+        *(f32x2*)(&sh.alpha[buf][pr][lane][0]) = f32x2{cnt0 ? alpha0 : 0.f, cnt1 ? alpha1 : 0.f};
+        xy = xy2; ab = ab2; co = co2;
+    }
+}
+
+// how a batch's pairs are shared out: the stager (which also gathers and culls) takes an eighth
+__device__ __forceinline__ void coop_share(const int n, const uint32_t w, int& p0, int& p1)
+{
+    const int nA = n >> 3, nB = (n - nA + 1) >> 1;
+    if (w == 0) { p0 = 0; p1 = nA; }
+    else if (w == 1) { p0 = nA; p1 = nA + nB; }
+    else { p0 = nA + nB; p1 = n; }
+}
+
+__device__ __forceinline__ void coop_producer(const RenderArgs& a, CoopShared& sh, const uint32_t lane,
+                                              const uint32_t w /* 0 = stager */, const uint2 range, const int total,
+                                              const uint32_t x0, const uint32_t y0)
+{
+    const float pixf_x = (float)(x0 + (lane & 7u)), pixf_y = (float)(y0 + (lane >> 3));
+    CO_DECL();
+    CO_BARRIER();   // the stager's prologue (batch 0)
+    for (int i = 0;; i++) {
+        const uint32_t first = sh.desc[i & 3][0], n = sh.desc[i & 3][1];
+        int p0, p1;
+        coop_share((int)n, w, p0, p1);
+#ifdef GSR_STATS
+        CO_T(te0); n_it++; n_x += (unsigned long long)(p1 - p0);
+#endif
+        coop_eval_pairs(sh, i & 1, first, p0, p1, lane, pixf_x, pixf_y);
+#ifdef GSR_STATS
+        { CO_T(te1); CO_ADD(tw_a, te0, te1); }
+#endif
+        CO_BARRIER();
+        if (sh.finished[i & 1]) break;
+    }
+    CO_STORE(w + 1u);
+}
+
+__device__ __forceinline__ void coop_stager(const RenderArgs& a, CoopShared& sh, const uint32_t lane, const uint2 range,
+                                            const int total, const uint32_t x0, const uint32_t y0)
+{
+    const float pixf_x = (float)(x0 + (lane & 7u)), pixf_y = (float)(y0 + (lane >> 3));
+    const float x0f = (float)x0, y0f = (float)y0;
+    const uint32_t* plist = a.point_list + range.x;
+    const int last = total - 1;
+    uint64_t live;
+    {
+        const bool inside = x0 + (lane & 7u) < (uint32_t)a.W && y0 + (lane >> 3) < (uint32_t)a.H;
+        live = __ballot(inside);
+    }
+    // gather pipeline as in quadrant_walk: records of the next round and ids of the round after are in flight
+    f32x4 c0, c1, n0, n1;
+    float c2b, n2b;
+    uint32_t id_cur, id_nxt, id_nn;
+    {
+        prefetch4(id_cur, plist + ((int)lane < total ? (int)lane : last));
+        prefetch4(id_nxt, plist + (64 + (int)lane < total ? 64 + (int)lane : last));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
+        const Splat* sp = a.splat + id_cur;
+        prefetch16(c0, &sp->q0);
+        prefetch16(c1, &sp->q1);
+        prefetch4f(c2b, &sp->q2);
+        retire_prefetch(c0, c1, c2b, id_nxt);
+    }
+    int base = 0;               // first list entry of the next round to cull
+    uint32_t S = 0;             // survivor slots appended so far (pads included); pair = S >> 1, may exceed the ring: used mod COOP_RING
+    uint32_t B0 = 0;            // pair at which the batch being formed starts
+    uint32_t marks_first = 0, marks_count = 0;   // slice boundaries crossed before the first entry of the batch being formed
+    bool list_end = total <= 0;
+    CO_DECL();
+
+    // appends an opacity-0 copy of the last survivor so that the stream holds whole pairs (alpha 0: never counts)
+    auto pad = [&]() {
+        if (S & 1u) {
+            const uint32_t pr = (S >> 1) % (uint32_t)COOP_RING;
+            if (lane == 0) {
+                float* p = &sh.prec[pr][0];
+                p[1] = p[0]; p[3] = p[2]; p[5] = p[4]; p[7] = p[6]; p[9] = p[8]; p[11] = 0.f;
+                float* cr = &sh.crec[pr][0];
+                cr[2] = cr[0]; cr[3] = cr[1]; cr[5] = cr[4];
+                ((uint32_t*)cr)[7] = ((const uint32_t*)cr)[6];
+            }
+            S++;
+        }
+    };
+    // forms the next batch and publishes it in desc[slot]; returns true if it was the last one
+    auto form = [&](const int slot) -> bool {
+        for (;;) {
+            if ((S >> 1) - B0 >= (uint32_t)COOP_BATCH) {   // a full batch is staged
+                if (lane == 0) {
+                    sh.desc[slot][0] = B0 % (uint32_t)COOP_RING; sh.desc[slot][1] = COOP_BATCH; sh.desc[slot][2] = 0;
+                    sh.desc[slot][3] = marks_first | (marks_count << 16);
+                }
+                B0 += COOP_BATCH; marks_count = 0;
+                return false;
+            }
+            if (list_end) {
+                pad();
+                if (lane == 0) {
+                    sh.desc[slot][0] = B0 % (uint32_t)COOP_RING; sh.desc[slot][1] = (S >> 1) - B0; sh.desc[slot][2] = 1;
+                    sh.desc[slot][3] = marks_first | (marks_count << 16);
+                }
+                B0 = S >> 1; marks_count = 0;
+                return true;
+            }
+            // the next round starts at a backward slice boundary: the consumer has to leave its state there, i.e. BEFORE any
+            // entry of that round is blended -> the batch being formed ends here
+            if (a.ckpt != nullptr && base != 0 && (base & (BWD_CHUNK - 1)) == 0 && (base >> BWD_CHUNK_SHIFT) < BWD_MAX_CHUNKS) {
+                const uint32_t k = (uint32_t)(base >> BWD_CHUNK_SHIFT);
+                const bool marked = marks_count != 0 && marks_first + marks_count > k;
+                if (!marked) {
+                    pad();
+                    if ((S >> 1) != B0) {          // entries before the boundary: they form a (short) batch of their own
+                        if (lane == 0) {
+                            sh.desc[slot][0] = B0 % (uint32_t)COOP_RING; sh.desc[slot][1] = (S >> 1) - B0; sh.desc[slot][2] = 0;
+                            sh.desc[slot][3] = marks_first | (marks_count << 16);
+                        }
+                        B0 = S >> 1;
+                        marks_first = k; marks_count = 1;
+                        return false;
+                    }
+                    if (marks_count == 0) marks_first = k;
+                    marks_count++;
+                }
+            }
+            // cull one round
+            {
+                const Splat* sp = a.splat + id_nxt;
+                prefetch16(n0, &sp->q0);
+                prefetch16(n1, &sp->q1);
+                prefetch4f(n2b, &sp->q2);
+                const int i2 = base + 128 + (int)lane;
+                prefetch4(id_nn, plist + (i2 < total ? i2 : last));
+            }
+            if (live != 0) {
+                int ax, ay, bx, by;
+                live_box(live, ax, ay, bx, by);
+                const bool valid = base + (int)lane < total;
+                const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f + (float)ax, y0f + (float)ay,
+                                                           x0f + (float)bx, y0f + (float)by);
+                const uint64_t mask = __ballot(touch);
+                if (mask != 0) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (touch) {
+                        const uint32_t slot_s = S + rank;
+                        const uint32_t pr = (slot_s >> 1) % (uint32_t)COOP_RING, half = slot_s & 1u;
+                        float* p = &sh.prec[pr][half];
+                        p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
+                        float* cr = &sh.crec[pr][0];
+                        *(f32x2*)(cr + 2 * half) = f32x2{c1.z, c1.w};
+                        cr[4 + half] = c2b;
+                        ((uint32_t*)cr)[6 + half] = (uint32_t)(base + (int)lane + 1);   // 1-based list position
+                    }
+                    S += (uint32_t)__popcll(mask);
+                }
+            }
+#ifdef GSR_STATS
+            CO_T(tr0); n_x++;
+#endif
+            retire_prefetch(n0, n1, n2b, id_nn);
+#ifdef GSR_STATS
+            { CO_T(tr1); CO_ADD(tw_b, tr0, tr1); }
+#endif
+            c0 = n0; c1 = n1; c2b = n2b;
+            id_cur = id_nxt;
+            id_nxt = id_nn;
+            base += 64;
+            if (base >= total) list_end = true;
+        }
+    };
+
+    bool was_last = form(0);
+    CO_BARRIER();
+    for (int i = 0;; i++) {
+#ifdef GSR_STATS
+        CO_T(tf0); n_it++;
+#endif
+        if (!was_last) {
+            was_last = form((i + 1) & 3);
+        } else if (lane == 0) {     // nothing is left to evaluate: an empty batch for the iteration in which the consumer finishes
+            sh.desc[(i + 1) & 3][0] = 0; sh.desc[(i + 1) & 3][1] = 0; sh.desc[(i + 1) & 3][2] = 1; sh.desc[(i + 1) & 3][3] = 0;
+        }
+#ifdef GSR_STATS
+        CO_T(tf1); CO_ADD(tw_a, tf0, tf1);
+#endif
+        const uint32_t first = sh.desc[i & 3][0], n = sh.desc[i & 3][1];
+        int p0, p1;
+        coop_share((int)n, 0u, p0, p1);
+        coop_eval_pairs(sh, i & 1, first, p0, p1, lane, pixf_x, pixf_y);
+#ifdef GSR_STATS
+        { CO_T(tf2); CO_ADD(tw_c, tf1, tf2); }
+#endif
+        CO_BARRIER();
+        if (sh.finished[i & 1]) break;
+        live = sh.live[i & 1];
+    }
+    CO_STORE(1u);
+}
+
+__device__ __forceinline__ void coop_consumer(const RenderArgs& a, CoopShared& sh, const uint32_t tile, const uint32_t q,
+                                              const uint32_t lane, const uint2 range, const int total, const uint32_t x0,
+                                              const uint32_t y0)
+{
+    const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
+    const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
+    float T = 1.0f;
+    f32x2 C01 = {0.f, 0.f};
+    float C2 = 0.f;
+    uint32_t last_contributor = 0, stop_at = 0;
+    bool crossed = false;
+    bool done = !inside;
+    float livef = done ? 0.f : 1.f;       // alphas of a terminated pixel are multiplied by 0: exactly "does not count"
+    bool all_done = __all(done);
+    bool finished = all_done;
+    CO_DECL();
+    CO_BARRIER();   // the stager's prologue (batch 0)
+    for (int i = 0;; i++) {
+#ifdef GSR_STATS
+        CO_T(tc0); n_it++;
+#endif
+        if (i >= 1 && !finished) {
+            const uint32_t* d = sh.desc[(i - 1) & 3];
+            const uint32_t first = d[0], marks = d[3];
+            const int npairs = (int)d[1];
+#ifdef GSR_STATS
+            n_x += (unsigned long long)npairs;
+#endif
+            const bool is_last = d[2] != 0;
+            const int cb = (i - 1) & 1;
+            // backward work items are slices of BWD_CHUNK list entries: leave the state at the boundaries this quadrant crosses
+            for (uint32_t k = marks & 0xFFFFu, e = k + (marks >> 16); k < e; k++) {
+                const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)k;
+                a.ckpt[slot * 256 + q * 64 + lane] = make_float4(T, C01.x, C01.y, C2);
+                crossed = true;
+            }
+            if (npairs > 0) {
+                uint32_t ring = first;
+                const float* cr = &sh.crec[ring][0];
+                f32x2 ae = *(const f32x2*)(&sh.alpha[cb][0][lane][0]);
+                f32x4 rg = *(const f32x4*)(cr + 0);
+                f32x2 bb = *(const f32x2*)(cr + 4);
+                uint2 pos = *(const uint2*)(cr + 6);
+                for (int pr = 0; pr < npairs; pr++) {
+                    // the next pair's operands are requested before this one is blended (one past the last is a valid address)
+                    if (++ring == (uint32_t)COOP_RING) ring = 0;
+                    const f32x2 ae_n = *(const f32x2*)(&sh.alpha[cb][(pr + 1) & (COOP_BATCH - 1)][lane][0]);
+                    const float* crn = &sh.crec[ring][0];
+                    const f32x4 rg_n = *(const f32x4*)(crn + 0);
+                    const f32x2 bb_n = *(const f32x2*)(crn + 4);
+                    const uint2 pos_n = *(const uint2*)(crn + 6);
+                    const f32x2 am = ae * livef;
+                    const float ae0 = am.x, ae1 = am.y;
+                    const float T1 = T * (1 - ae0), T2 = T1 * (1 - ae1);
+                    if (!__any(T2 < 0.0001f)) {
+                        const f32x2 rg0 = {rg.x, rg.y}, rg1 = {rg.z, rg.w};
+                        C01 += rg0 * ae0 * T;
+                        C2 += bb.x * ae0 * T;
+                        C01 += rg1 * ae1 * T1;
+                        C2 += bb.y * ae1 * T1;
+                        last_contributor = ae0 != 0.f ? pos.x : last_contributor;
+                        last_contributor = ae1 != 0.f ? pos.y : last_contributor;
+                        T = T2;
+                    } else {
+                        // some pixel stops inside this pair (see quadrant_walk)
+                        const bool cnt0 = ae0 != 0.f, cnt1 = ae1 != 0.f;
+                        const bool s0 = cnt0 && (T1 < 0.0001f);
+                        const bool s1 = !s0 && cnt1 && (T2 < 0.0001f);
+                        const bool b0 = cnt0 && !s0, b1 = cnt1 && !s0 && !s1;
+                        const float be0 = b0 ? ae0 : 0.f, be1 = b1 ? ae1 : 0.f;
+                        const float U1 = T * (1 - be0), U2 = U1 * (1 - be1);
+                        const f32x2 rg0 = {rg.x, rg.y}, rg1 = {rg.z, rg.w};
+                        C01 += rg0 * be0 * T;
+                        C2 += bb.x * be0 * T;
+                        C01 += rg1 * be1 * U1;
+                        C2 += bb.y * be1 * U1;
+                        last_contributor = b0 ? pos.x : last_contributor;
+                        last_contributor = b1 ? pos.y : last_contributor;
+                        T = U2;
+                        stop_at = s0 ? pos.x : (s1 ? pos.y : stop_at);
+                        done = done || s0 || s1;
+                        livef = done ? 0.f : 1.f;
+                        all_done = __ballot(!done) == 0;
+                        if (all_done) break;
+                    }
+                    ae = ae_n; rg = rg_n; bb = bb_n; pos = pos_n;
+                }
+            }
+            finished = all_done || is_last;
+        }
+        const uint64_t live_now = __ballot(!done);    // (taken by the whole wave, stored by one lane)
+        if (lane == 0) {
+            sh.live[i & 1] = live_now;
+            sh.finished[i & 1] = finished ? 1u : 0u;
+        }
+#ifdef GSR_STATS
+        { CO_T(tc1); CO_ADD(tw_a, tc0, tc1); }
+#endif
+        CO_BARRIER();
+        if (finished) break;
+    }
+    CO_STORE(0u);
+
+    {
+        uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(need, d, 64);
+            need = need > o ? need : o;
+        }
+        if (lane == 0 && need != 0) atomicMax(&a.tile_need[tile], need);
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
+        a.final_T[pix] = T;
+        a.n_contrib[pix] = last_contributor;
+        a.out_color[pix] = C01.x + T * a.bg[0];
+        a.out_color[N + pix] = C01.y + T * a.bg[1];
+        a.out_color[2 * N + pix] = C2 + T * a.bg[2];
+        if (crossed) {
+            a.accum[pix] = C01.x;
+            a.accum[N + pix] = C01.y;
+            a.accum[2 * N + pix] = C2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_render_forward_coop(RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) CoopLds lds;
+    uint32_t view, tile, q;
+    if (!locate_work(a, view, tile, q)) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+    if (total < COOP_MIN_LIST) {
+        // short list: the q == 0 workgroup's four waves take one quadrant each
+        if (q != 0) return;
+        quadrant_walk<0>(a, view, tile, wave, lane, lds.light[wave]);
+        return;
+    }
+    const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
+    const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
+    if (x0 >= (uint32_t)a.W || y0 >= (uint32_t)a.H) return;   // quadrant entirely outside the image: nothing to write
+    if (wave == 0) coop_consumer(a, lds.co, tile, q, lane, range, total, x0, y0);
+    else if (wave == 1) coop_stager(a, lds.co, lane, range, total, x0, y0);
+    else coop_producer(a, lds.co, lane, wave - 1u, range, total, x0, y0);
+}
+
+// Batches of up to this many views use the cooperative kernel: with more views in one launch the chip is full of
+// independent quadrant waves and the deep walks of one view hide behind the bulk of the others.
+// GSR_COOP_MAX_VIEWS overrides (0 = never), for measurements.
+static int coop_max_views()
+{
+    static const int v = [] {
+        const char* e = getenv("GSR_COOP_MAX_VIEWS");
+        return e ? atoi(e) : 0;   // (off by default until it beats the single-wave walk)
+    }();
+    return v;
+}
+
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
                           bool with_ckpt, const ExtraChannels* X)
 {
@@ -530,6 +1007,8 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
         a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out;
         if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
         else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
+    } else if (B.V <= coop_max_views()) {
+        hipLaunchKernelGGL(k_render_forward_coop, grid, dim3(256), 0, L.stream, a);
     } else {
         hipLaunchKernelGGL(k_render_forward<0>, grid, dim3(64), 0, L.stream, a);
     }
