@@ -34,3 +34,5 @@ for v in (0, 1, 5):
         print("  %-9s %6d waves, mean life %7.2f us, longest %7.2f us | " % (name, o[7], o[0] * 0.01 / o[7], int(out[24 + r]) * 0.01) +
               ", ".join("%s %.1f%%" % (labels[i], 100.0 * o[i] / max(o[0], 1)) for i in (1, 2, 3, 4) if labels[i] != "-") +
               " | %s %.1f, %s %.1f per wave" % (labels[5], o[5] / o[7], labels[6], o[6] / o[7]))
+    print("  consumer timeline: last end %.1f us after the first start; mean start %.1f us, last start %.1f us; %d waves live > 80 us, their mean start %.1f us"
+          % (int(out[27]) * 0.01, int(out[30]) * 0.01, int(out[31]) * 0.01, int(out[29]), int(out[28]) * 0.01))
