@@ -14,8 +14,6 @@
 //   - pairs beyond the binning arena's capacity are counted but not written (the host retries with a larger arena).
 // Tile ranges (reference CR/rasterizer_impl.cu:116-138 identifyTileRanges + the memset at :310): one thread per tile finds
 // its list in the sorted keys by binary search -- T searches instead of a pass over all R keys.
-#include <cstdlib>
-
 #include "common.hpp"
 
 namespace gsr {
@@ -341,10 +339,8 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 // One 1024-thread workgroup per view: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
 // wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
 // one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
-// fold != 0 (experiment, GSR_ORDER_FOLD): lists longer than `fold` entries are ranked as fold^2 / length -- among long lists the
-// shorter ones are the likelier to be walked to the end (silhouette tiles), the longest belong to opaque interiors that stop early
 __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
-                                                     size_t iv_stride, uint32_t fold)
+                                                     size_t iv_stride)
 {
     ranges = at_view(ranges, iv_stride, blockIdx.x);
     tile_order = at_view(tile_order, iv_stride, blockIdx.x);
@@ -359,11 +355,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
         for (int t = threadIdx.x; t < T_pad; t += 1024) {
             const bool ok = t < T;
             uint32_t b = 0;
-            if (ok) {
-                uint32_t len = ranges[t].y - ranges[t].x;
-                if (fold != 0 && len > fold) len = (uint32_t)(((uint64_t)fold * fold) / len) + 1u;
-                b = work_bucket(len);
-            }
+            if (ok) b = work_bucket(ranges[t].y - ranges[t].x);
             const bool empty = ok && b == ORD_BUCKETS - 1;
             const uint64_t em = __ballot(empty);
             uint32_t slot = 0;
@@ -400,8 +392,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
 
 int launch_tile_order(const Launch& L, const Batch& B, int T)
 {
-    static const uint32_t fold = [] { const char* e = getenv("GSR_ORDER_FOLD"); return e ? (uint32_t)atoi(e) : 0u; }();
-    hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride, fold);
+    hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride);
     return check_launch(L, "tile_order");
 }
 

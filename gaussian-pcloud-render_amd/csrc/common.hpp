@@ -121,8 +121,7 @@ struct BinView {
 
 struct ImageView {
     uint32_t* tile_need;  // [T] entries walked by the forward render  } cleared by k_preprocess at the start of
-    uint32_t* bwd_count;  // [4] number of backward items, number of     } every frame
-                          //     forward continuation items
+    uint32_t* bwd_count;  // [4] number of backward items              } every frame
     uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
@@ -130,8 +129,6 @@ struct ImageView {
     float* accum;         // [3N] colour accumulated by the forward render, without the background term (only written
                           //      for quadrants that crossed a BWD_CHUNK boundary: the only ones whose backward reads it)
     uint32_t* bwd_items;  // [BWD_MAX_CHUNKS * T] backward work items: tile | chunk << BWD_TILE_BITS, heaviest first
-    uint32_t* cont_items; // [4 T] quadrants the forward's first phase left unfinished: tile | q << BWD_TILE_BITS (render_fwd.hip);
-                          //       their count is bwd_count[1]
     char* zero_begin;
     size_t zero_bytes;
     size_t bytes;
@@ -213,7 +210,6 @@ inline ImageView image_view(void* base, int W, int H)
     carve(cur, v.tile_order, T ? T : 1);
     carve(cur, v.accum, 3 * (N ? N : 1));
     carve(cur, v.bwd_items, (size_t)BWD_MAX_CHUNKS * (T ? T : 1));
-    carve(cur, v.cont_items, (size_t)8 * (T ? T : 1));
     v.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return v;
 }
@@ -297,7 +293,6 @@ int debug_bwd_stats(unsigned long long* out8, int reset);   // instrumentation b
 int debug_dup_times(unsigned long long* out8, int reset);
 int debug_scatter_times(unsigned long long* out8, int reset);
 int debug_fwd_times(unsigned long long* out8, int reset);
-int debug_coop_times(unsigned long long* out32, int reset);
 int debug_bwd_times(unsigned long long* out8, int reset);
 #endif
 // preprocess_bwd.hip

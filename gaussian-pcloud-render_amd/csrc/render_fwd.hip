@@ -26,8 +26,6 @@
 // k_render_forward<NX>, NX = 4 or 8: the same walk also composites NX extra per-Gaussian channels with the colour's alphas
 // (gsr_forward_batch_channels: the reference's callers render world xyz, a hit map and normals as three more full passes,
 // simple_raw_render.py:410-524).  The extra values ride in the pair records next to the colour; NX = 0 is the plain kernel.
-#include <cstdlib>
-
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -54,11 +52,6 @@ struct RenderArgs {
     const float* extra_scale;  // [V][NX] per-view factors applied to them (NULL: 1), e.g. the +-1 of view-dependent normals
     const float* bg_extra;     // [NX]
     float* out_extra;          // [V][NX][H][W]
-    // two-phase forward (small batches): quadrant_walk stops after `cap` list entries and leaves the quadrants that are not
-    // finished by then to k_render_forward_cont, as work items tile | q << BWD_TILE_BITS
-    int cap;                   // 0: walk whole lists; else the pairs a quadrant blends before it is handed over
-    uint32_t* cont_items;      // [4 T][2]: tile | q << BWD_TILE_BITS, list position reached | crossed a slice boundary << 31
-    uint32_t* cont_count;      // [1], cleared at the start of the frame
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -185,18 +178,24 @@ int debug_fwd_times(unsigned long long* out8, int reset)
 }
 #endif
 
-// XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant workgroups of
-// one tile are b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records are fetched into
-// that L2 once instead of four times.
-// Batches: groups of 32 workgroups (8 tiles x 4 quadrants) are dealt to the views round-robin, so the heaviest tiles of
-// EVERY view are dispatched first and the batch has one tail instead of one per view.
-// Returns false when the workgroup has no tile; otherwise `a` points at the view's arrays.
-__device__ __forceinline__ bool locate_work(RenderArgs& a, uint32_t& view, uint32_t& tile, uint32_t& q)
+template <int NX>
+__global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 {
+#ifdef GSR_STATS
+    FW_T(tw0);
+    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
+#endif
+    static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
+    constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
+    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of
+    // one tile are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the tile's list and Splat records
+    // are fetched into that L2 once instead of four times.
+    // Batches: groups of 32 workgroups (8 tiles x 4 quadrants) are dealt to the views round-robin, so the heaviest tiles of
+    // EVERY view are dispatched first and the batch has one tail instead of one per view.
     const uint32_t group = blockIdx.x >> 5;
-    view = group % a.V;
+    const uint32_t view = group % a.V;
     const uint32_t order_slot = (group / a.V) * 8u + (blockIdx.x & 7u);
-    if (order_slot >= (uint32_t)a.num_tiles) return false;
+    if (order_slot >= (uint32_t)a.num_tiles) return;
     a.ranges = at_view(a.ranges, a.iv_stride, view);
     a.tile_order = at_view(a.tile_order, a.iv_stride, view);
     a.final_T = at_view(a.final_T, a.iv_stride, view);
@@ -207,27 +206,9 @@ __device__ __forceinline__ bool locate_work(RenderArgs& a, uint32_t& view, uint3
     if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
     a.splat = at_view(a.splat, a.g_stride, view);
     a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
-    if (a.cap != 0) {
-        a.cont_items = at_view(a.cont_items, a.iv_stride, view);
-        a.cont_count = at_view(a.cont_count, a.iv_stride, view);
-    }
-    tile = a.tile_order[order_slot];
-    q = (blockIdx.x >> 3) & 3u;
-    return true;
-}
-
-// One wave64 walks the list of `tile` for the 8x8 quadrant q on its own (header comment).  `stage`: 33 * (PAIR_WORDS + 2 NX)
-// floats of LDS that belong to the calling wave.
-template <int NX>
-__device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_t view, const uint32_t tile, const uint32_t q,
-                                              const uint32_t lane, float* __restrict__ stage)
-{
-#ifdef GSR_STATS
-    FW_T(tw0);
-    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
-#endif
-    static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
-    constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
+    const uint32_t tile = a.tile_order[order_slot];
+    const uint32_t q = (blockIdx.x >> 3) & 3u;
+    const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
     const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
     const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
@@ -238,11 +219,10 @@ __device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_
     // keep entries that can reach one of those
     float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 7.f;
 
+    __shared__ __attribute__((aligned(16))) float stage[33 * PW];   // 32 pairs + one that may be read, never used
+
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
-    // two-phase forward: the walk is handed over (at a round boundary) once it has blended a.cap pairs
-    int pairs_left = a.cap != 0 ? a.cap : 0x7FFFFFFF;
-    int walk_end = total;                       // set to the hand-over position when the budget runs out
 
     float T = 1.0f;
     f32x2 C01 = {0.f, 0.f};
@@ -296,10 +276,6 @@ __device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_
             }
         }
         for (int base = 0; base < total; base += 64) {
-            if (NX == 0 && pairs_left <= 0) {
-                walk_end = base;
-                break;
-            }
             {
                 const Splat* sp = a.splat + id_nxt;
                 prefetch16(n0, &sp->q0);
@@ -446,7 +422,6 @@ __device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_
                 // The next pair is always read (the staging area has a spare pair, so reading one past the last is harmless)
                 // and the loop ends on the pair count alone: when every pixel is done the count is set to 0.
                 int npairs = (int)((nsurv + 1u) >> 1);
-                if (NX == 0) pairs_left -= npairs;
                 int pair = 0;
 #ifdef GSR_STATS
                 FW_T(ts1);
@@ -493,33 +468,14 @@ __device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_
 #endif
     // instrumentation: how many list entries this tile really needed (max over its pixels); tile_need is zeroed
     // before the launch
-    // Not finished at the cap: the walk is continued by k_render_forward_cont.  The per-pixel state travels in the arrays the
-    // final results go to anyway: final_T (negative = the pixel has terminated), n_contrib, accum.
-    const bool to_be_continued = walk_end < total && !all_done;
     {
-        uint32_t need = inside ? (done ? stop_at : (to_be_continued ? 0u : (uint32_t)total)) : 0u;
+        uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             const uint32_t o = __shfl_xor(need, d, 64);
             need = need > o ? need : o;
         }
         if (lane == 0 && need != 0) atomicMax(&a.tile_need[tile], need);
-    }
-    if (NX == 0 && to_be_continued) {
-        if (inside) {
-            const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
-            a.final_T[pix] = done ? -T : T;
-            a.n_contrib[pix] = last_contributor;
-            a.accum[pix] = C01.x;
-            a.accum[N + pix] = C01.y;
-            a.accum[2 * N + pix] = C2;
-        }
-        if (lane == 0) {
-            const uint32_t slot = atomicAdd(a.cont_count, 1u);
-            a.cont_items[2 * slot] = tile | (q << BWD_TILE_BITS);
-            a.cont_items[2 * slot + 1] = (uint32_t)walk_end | (crossed ? 0x80000000u : 0u);
-        }
-        return;
     }
 
     if (inside) {
@@ -543,541 +499,6 @@ __device__ __forceinline__ void quadrant_walk(const RenderArgs& a, const uint32_
             a.accum[2 * N + pix] = C2;
         }
     }
-}
-
-template <int NX>
-__global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float stage[33 * (PAIR_WORDS + 2 * NX)];   // 32 pairs + one that may be read, never used
-    uint32_t view, tile, q;
-    if (!locate_work(a, view, tile, q)) return;
-    quadrant_walk<NX>(a, view, tile, q, threadIdx.x, stage);
-}
-
-
-// ---- cooperative quadrants: the deep walks of the drop-in (one view per call) forward ----------------------------------
-// A single view's launch is over when its deepest list walks are: a quadrant wave walks its list serially, at the
-// cadence of a lone wave, and ~70 instructions per entry pair are spent on what does NOT depend on the walk -- the gather, the
-// footprint test, power / exp / alpha of every entry for every pixel.  Only the blend is sequential: T *= (1 - alpha),
-// C += c * alpha * T, the stop test.  On the benchmark view 85 % of the quadrants are finished after 2 048 entries and the
-// launch then waits ~0.15 ms for the silhouette tiles that walk 4 - 5 000.  So small batches render in two phases:
-// k_render_forward walks every list up to COOP_CAP entries and queues the quadrants that are not finished
-// (quadrant_walk, `cap`); k_render_forward_cont gives each of those to a workgroup of four waves:
-//   wave 1 (stager): gathers 64 list entries per round, runs the footprint test against the pixels still live and appends
-//     the survivors, compacted in pairs, to the staged records in LDS; cuts the stream into BATCHES of COOP_BATCH pairs;
-//   waves 1..3 (producers): evaluate alpha of a batch's pairs for all 64 pixels -- the packed evaluation of quadrant_walk,
-//     term for term -- and write (alpha or 0) rows into an LDS buffer;
-//   wave 0 (consumer): takes over the per-pixel state phase one left, walks the rows of the previous batch in list order and
-//     does nothing but the reference's sequential part (CR/forward.cu:328-365): T * (1 - alpha), the stop test,
-//     C += c * alpha * T, last contributor.
-// One barrier per batch; alpha rows are double buffered, so batch i + 1 is being staged and batch i evaluated while the
-// consumer blends batch i - 1.  The values blended and their order are those of quadrant_walk, hence of the reference:
-// out_color, final_T, n_contrib, tile_need and the slice-boundary state are bit-identical to the single-wave walk (every
-// forward parity test of a single view runs through both phases; GSR_COOP_CAP=64 in the tests' second pass sends almost
-// every quadrant through the cooperative kernel).  The footprint test sees the live pixels two or three batches late,
-// which keeps it conservative (a terminated pixel has T = 0 in the consumer).
-// (Splitting EVERY quadrant over four waves was measured first: 4 wave slots per quadrant for the same residency make the
-// launch slower, 0.28 vs 0.26 ms -- the chip runs out of slots, not out of issue cycles.)
-#ifdef GSR_STATS
-// instrumentation build only: per-wave time split of the cooperative kernel's LAST launch (10-ns ticks), one record per wave:
-// 0 life, 1 in barriers, 2 role work A (consumer: blending; stager: forming batches; producer: evaluating), 3 role work B (stager:
-// waiting for gathered records), 4 role work C (stager: evaluating), 5 iterations, 6 pairs / rounds, 7 role + 1
-constexpr int CO_REC = 1 << 18;
-__device__ unsigned g_coop_rec[CO_REC][8];
-#define CO_T(var) const unsigned long long var = wall_clock64()
-#define CO_ADD(acc, a_, b_) acc += (b_) - (a_)
-int debug_coop_times(unsigned long long* out32, int reset)
-{
-    static unsigned host[CO_REC][8];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_coop_rec), sizeof(host)) != hipSuccess) return -1;
-    for (int i = 0; i < 32; i++) out32[i] = 0;
-    for (int r = 0; r < CO_REC; r++) {
-        const unsigned role = host[r][7];
-        if (role == 0 || role > 3) continue;
-        unsigned long long* o = out32 + 8 * (role - 1);
-        for (int i = 0; i < 7; i++) o[i] += host[r][i];
-        o[7]++;
-        if (host[r][0] > out32[24 + role - 1]) out32[24 + role - 1] = host[r][0];   // the longest-lived wave of the role
-    }
-    {   // timeline of the consumer waves: first start, and start / end of the 8 longest-lived ones (relative to the first start)
-        unsigned t0 = 0xFFFFFFFFu, tend = 0;
-        for (int r = 0; r < CO_REC; r++)
-            if (host[r][7] == 1) { if (host[r][3] < t0) t0 = host[r][3]; }
-        for (int r = 0; r < CO_REC; r++)
-            if (host[r][7] == 1 && host[r][4] - t0 > tend) tend = host[r][4] - t0;
-        out32[27] = tend;                      // last consumer end
-        unsigned long long late = 0, n = 0;
-        for (int r = 0; r < CO_REC; r++)
-            if (host[r][7] == 1 && host[r][0] > 8000) { late += host[r][3] - t0; n++; }   // waves living longer than 80 us
-        out32[28] = n ? late / n : 0;          // their mean start
-        out32[29] = n;
-        unsigned long long startsum = 0, cnt = 0; unsigned laststart = 0;
-        for (int r = 0; r < CO_REC; r++)
-            if (host[r][7] == 1) { startsum += host[r][3] - t0; cnt++; if (host[r][3] - t0 > laststart) laststart = host[r][3] - t0; }
-        out32[30] = cnt ? startsum / cnt : 0;  // mean start of all consumers
-        out32[31] = laststart;                 // last start
-    }
-    if (reset) {
-        for (int r = 0; r < CO_REC; r++) for (int i = 0; i < 8; i++) host[r][i] = 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_rec), host, sizeof(host)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#define CO_BARRIER() do { CO_T(tb0_); __syncthreads(); CO_T(tb1_); CO_ADD(tw_bar, tb0_, tb1_); } while (0)
-#define CO_DECL() CO_T(tw0); unsigned long long tw_bar = 0, tw_a = 0, tw_b = 0, tw_c = 0, n_it = 0, n_x = 0
-#define CO_STORE(role) do { if (lane == 0) { const unsigned ri = blockIdx.x * 4u + (role); if (ri < (unsigned)CO_REC) { CO_T(tw1); unsigned* r_ = g_coop_rec[ri]; \
-    r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_bar; r_[2] = (unsigned)tw_a; r_[3] = (unsigned)tw_b; r_[4] = (unsigned)tw_c; \
-    r_[5] = (unsigned)n_it; r_[6] = (unsigned)n_x; r_[7] = (role) >= 2u ? 3u : (role) + 1u; } } } while (0)
-#else
-#define CO_BARRIER() __syncthreads()
-#define CO_DECL() do { } while (0)
-#define CO_STORE(role) do { } while (0)
-#endif
-
-constexpr int COOP_BATCH = 16;        // pairs per batch
-constexpr int COOP_SLOTS = 6;         // batch slots of staged records: batch i - 1 (consumer), i (producers), i + 1 .. i + 3 (staged)
-__device__ __forceinline__ uint32_t coop_slot(uint32_t batch) { return batch % (uint32_t)COOP_SLOTS; }
-// the three evaluating waves share a batch's 16 pair positions statically; the stager (which also gathers and culls) takes two
-__device__ __forceinline__ constexpr int coop_p0(int w) { return w == 0 ? 0 : w == 1 ? 2 : 9; }
-__device__ __forceinline__ constexpr int coop_p1(int w) { return w == 0 ? 2 : w == 1 ? 9 : 16; }
-
-struct CoopShared {
-    float alpha[2][COOP_BATCH][64][2];           // (alpha or 0) of the pair's two entries, per pixel                   16 KB
-    uint32_t hitpos[2][COOP_BATCH][64];          // list position of the pair's last entry that counts for the pixel (0: none)  8 KB
-    float prec[COOP_SLOTS][COOP_BATCH][12];      // producers' record of a pair: x0 x1 y0 y1 | A0 A1 B0 B1 | C0 C1 o0 o1
-    float crec[COOP_SLOTS][COOP_BATCH][8];       // consumer's record of a pair: r0 g0 r1 g1 | b0 b1 pos0 pos1
-    uint32_t desc[4][4];                         // batch i in slot i & 3: batch slot, pairs, last batch, slice boundaries (first | count << 16)
-    uint64_t live[2];                            // pixels not yet terminated, as of the end of iteration i (slot i & 1)
-    uint32_t finished[2];                        // the consumer is done: every pixel terminated, or the last batch has been blended
-};
-
-// Alpha rows of this wave's pair positions [p0, p1) of a batch (n pairs staged in batch slot bs): positions past n get zero
-// rows and zero colours, so that the consumer can blend all COOP_BATCH positions without looking at n.
-__device__ __forceinline__ void coop_eval_pairs(CoopShared& sh, const int buf, const uint32_t bs, const int n, const int p0, const int p1,
-                                                const uint32_t w, const uint32_t lane, const float pixf_x, const float pixf_y)
-{
-    const int pe = p1 < n ? p1 : n;      // staged positions of the range: [p0, pe)
-    if (p0 < pe) {
-        const float* r = &sh.prec[bs][p0][0];
-        const uint32_t* c = reinterpret_cast<const uint32_t*>(&sh.crec[bs][p0][6]);
-        float* al = &sh.alpha[buf][p0][lane][0];
-        uint32_t* hp = &sh.hitpos[buf][p0][lane];
-        f32x4 xy = *(const f32x4*)(r + 0), ab = *(const f32x4*)(r + 4), co = *(const f32x4*)(r + 8);
-        uint2 pos = *(const uint2*)c;
-#pragma unroll 1
-        for (int pr = p0; pr < pe; pr++) {
-            // the next pair is read from LDS while this one is evaluated (one past the range is a valid address)
-            r += 12; c += 8;
-            const f32x4 xy2 = *(const f32x4*)(r + 0), ab2 = *(const f32x4*)(r + 4), co2 = *(const f32x4*)(r + 8);
-            const uint2 pos2 = *(const uint2*)c;
-            const f32x2 X = {xy.x, xy.y}, Y = {xy.z, xy.w}, A2 = {ab.x, ab.y}, B2 = {ab.z, ab.w};
-            const f32x2 C2p = {co.x, co.y}, O2 = {co.z, co.w};
-            const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
-            const f32x2 power = -0.5f * (A2 * dx * dx + C2p * dy * dy) - B2 * dx * dy;
-            const f32x2 alv = O2 * exp_nonpos2(power);
-            const float alpha0 = fminf(0.99f, alv.x), alpha1 = fminf(0.99f, alv.y);
-            const bool cnt0 = !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f);
-            const bool cnt1 = !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f);
-            *(f32x2*)al = f32x2{cnt0 ? alpha0 : 0.f, cnt1 ? alpha1 : 0.f};
-            al += 128;
-            *hp = cnt1 ? pos.y : (cnt0 ? pos.x : 0u);
-            hp += 64;
-            xy = xy2; ab = ab2; co = co2; pos = pos2;
-        }
-    }
-    for (int pr = p0 > n ? p0 : n; pr < p1; pr++) {   // short batch (a slice boundary or the end of the list)
-        *(f32x2*)(&sh.alpha[buf][pr][lane][0]) = f32x2{0.f, 0.f};
-        sh.hitpos[buf][pr][lane] = 0u;
-        if (lane < 6) sh.crec[bs][pr][lane] = 0.f;    // colours of an empty position: 0 * alpha 0, never NaN
-    }
-}
-
-__device__ __forceinline__ void coop_producer(const RenderArgs& a, CoopShared& sh, const uint32_t lane, const uint32_t w,
-                                              const uint32_t x0, const uint32_t y0)
-{
-    const float pixf_x = (float)(x0 + (lane & 7u)), pixf_y = (float)(y0 + (lane >> 3));
-    const int p0 = w == 1 ? coop_p0(1) : coop_p0(2), p1 = w == 1 ? coop_p1(1) : coop_p1(2);
-    CO_DECL();
-    CO_BARRIER();   // the stager's prologue (batch 0)
-    for (int i = 0;; i++) {
-        const uint32_t bs = sh.desc[i & 3][0], n = sh.desc[i & 3][1];
-#ifdef GSR_STATS
-        CO_T(te0); n_it++; n_x += (unsigned long long)(p1 - p0);
-#endif
-        coop_eval_pairs(sh, i & 1, bs, (int)n, p0, p1, w, lane, pixf_x, pixf_y);
-#ifdef GSR_STATS
-        { CO_T(te1); CO_ADD(tw_a, te0, te1); }
-#endif
-        CO_BARRIER();
-        if (sh.finished[i & 1]) break;
-    }
-    CO_STORE(w + 1u);
-}
-
-__device__ __forceinline__ void coop_stager(const RenderArgs& a, CoopShared& sh, const uint32_t lane, const uint2 range,
-                                            const int total, const int start, const uint32_t x0, const uint32_t y0)
-{
-    const float pixf_x = (float)(x0 + (lane & 7u)), pixf_y = (float)(y0 + (lane >> 3));
-    const float x0f = (float)x0, y0f = (float)y0;
-    const uint32_t* plist = a.point_list + range.x;
-    const int last = total - 1;
-    uint64_t live;
-    {
-        // the pixels phase one left alive (final_T > 0; see quadrant_walk)
-        const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
-        const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
-        live = __ballot(inside && a.final_T[(size_t)py * a.W + px] > 0.f);
-    }
-    // gather pipeline as in quadrant_walk: records of the next round and ids of the round after are in flight
-    f32x4 c0, c1, n0, n1;
-    float c2b, n2b;
-    uint32_t id_cur, id_nxt, id_nn;
-    int base = start;           // first list entry of the next round to cull (phase one walked [0, start))
-    {
-        const int i0 = base + (int)lane, i1 = i0 + 64;
-        prefetch4(id_cur, plist + (i0 < total ? i0 : last));
-        prefetch4(id_nxt, plist + (i1 < total ? i1 : last));
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
-        const Splat* sp = a.splat + id_cur;
-        prefetch16(c0, &sp->q0);
-        prefetch16(c1, &sp->q1);
-        prefetch4f(c2b, &sp->q2);
-        retire_prefetch(c0, c1, c2b, id_nxt);
-    }
-    // The stream of survivors is cut into batches; nb = number of the batch being formed, S = survivor slots staged from its
-    // start on (pads included): slot s lives in batch nb + (s >> 5), pair (s >> 1) & 15, half s & 1.
-    uint32_t nb = 0, S = 0;
-    uint32_t marks_first = 0, marks_count = 0;   // slice boundaries crossed before the first entry of the batch being formed
-    bool list_end = base >= total;
-    CO_DECL();
-
-    // appends an opacity-0 copy of the last survivor so that the stream holds whole pairs (alpha 0: never counts)
-    auto pad = [&]() {
-        if (S & 1u) {
-            if (lane == 0) {
-                float* p = &sh.prec[coop_slot(nb + (S >> 5))][(S >> 1) & 15u][0];
-                p[1] = p[0]; p[3] = p[2]; p[5] = p[4]; p[7] = p[6]; p[9] = p[8]; p[11] = 0.f;
-                float* cr = &sh.crec[coop_slot(nb + (S >> 5))][(S >> 1) & 15u][0];
-                cr[2] = cr[0]; cr[3] = cr[1]; cr[5] = cr[4];
-                ((uint32_t*)cr)[7] = ((const uint32_t*)cr)[6];
-            }
-            S++;
-        }
-    };
-    auto publish = [&](const int slot, const uint32_t n, const uint32_t is_last) {
-        if (lane == 0) {
-            sh.desc[slot][0] = coop_slot(nb); sh.desc[slot][1] = n; sh.desc[slot][2] = is_last;
-            sh.desc[slot][3] = marks_first | (marks_count << 16);
-        }
-        marks_count = 0;
-    };
-    // forms the next batch and publishes it in desc[slot]; returns true if it was the last one
-    auto form = [&](const int slot) -> bool {
-        for (;;) {
-            if (S >= 2u * COOP_BATCH) {   // a full batch is staged
-                publish(slot, COOP_BATCH, 0u);
-                nb++; S -= 2u * COOP_BATCH;
-                return false;
-            }
-            if (list_end) {
-                pad();
-                publish(slot, S >> 1, 1u);
-                nb++; S = 0;
-                return true;
-            }
-            // the next round starts at a backward slice boundary: the consumer has to leave its state there, i.e. BEFORE any
-            // entry of that round is blended -> the batch being formed ends here
-            if (a.ckpt != nullptr && base != 0 && (base & (BWD_CHUNK - 1)) == 0 && (base >> BWD_CHUNK_SHIFT) < BWD_MAX_CHUNKS) {
-                const uint32_t k = (uint32_t)(base >> BWD_CHUNK_SHIFT);
-                const bool marked = marks_count != 0 && marks_first + marks_count > k;
-                if (!marked) {
-                    pad();
-                    if (S != 0) {          // entries before the boundary: they form a (short) batch of their own
-                        publish(slot, S >> 1, 0u);
-                        nb++; S = 0;
-                        marks_first = k; marks_count = 1;
-                        return false;
-                    }
-                    if (marks_count == 0) marks_first = k;
-                    marks_count++;
-                }
-            }
-            // cull one round
-            {
-                const Splat* sp = a.splat + id_nxt;
-                prefetch16(n0, &sp->q0);
-                prefetch16(n1, &sp->q1);
-                prefetch4f(n2b, &sp->q2);
-                const int i2 = base + 128 + (int)lane;
-                prefetch4(id_nn, plist + (i2 < total ? i2 : last));
-            }
-            if (live != 0) {
-                int ax, ay, bx, by;
-                live_box(live, ax, ay, bx, by);
-                const bool valid = base + (int)lane < total;
-                const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, x0f + (float)ax, y0f + (float)ay,
-                                                           x0f + (float)bx, y0f + (float)by);
-                const uint64_t mask = __ballot(touch);
-                if (mask != 0) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (touch) {
-                        const uint32_t ss = S + rank;
-                        const uint32_t bsl = coop_slot(nb + (ss >> 5)), pr = (ss >> 1) & 15u, half = ss & 1u;
-                        float* p = &sh.prec[bsl][pr][half];
-                        p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
-                        float* cr = &sh.crec[bsl][pr][0];
-                        *(f32x2*)(cr + 2 * half) = f32x2{c1.z, c1.w};
-                        cr[4 + half] = c2b;
-                        ((uint32_t*)cr)[6 + half] = (uint32_t)(base + (int)lane + 1);   // 1-based list position
-                    }
-                    S += (uint32_t)__popcll(mask);
-                }
-            }
-#ifdef GSR_STATS
-            CO_T(tr0); n_x++;
-#endif
-            retire_prefetch(n0, n1, n2b, id_nn);
-#ifdef GSR_STATS
-            { CO_T(tr1); CO_ADD(tw_b, tr0, tr1); }
-#endif
-            c0 = n0; c1 = n1; c2b = n2b;
-            id_cur = id_nxt;
-            id_nxt = id_nn;
-            base += 64;
-            if (base >= total) list_end = true;
-        }
-    };
-
-    bool was_last = form(0);
-    CO_BARRIER();
-    for (int i = 0;; i++) {
-#ifdef GSR_STATS
-        CO_T(tf0); n_it++;
-#endif
-        if (!was_last) {
-            was_last = form((i + 1) & 3);
-        } else if (lane == 0) {     // nothing is left to evaluate: an empty batch for the iteration in which the consumer finishes
-            sh.desc[(i + 1) & 3][0] = coop_slot(nb); sh.desc[(i + 1) & 3][1] = 0; sh.desc[(i + 1) & 3][2] = 1;
-            sh.desc[(i + 1) & 3][3] = 0;
-        }
-#ifdef GSR_STATS
-        CO_T(tf1); CO_ADD(tw_a, tf0, tf1);
-#endif
-        const uint32_t bs = sh.desc[i & 3][0], n = sh.desc[i & 3][1];
-        coop_eval_pairs(sh, i & 1, bs, (int)n, coop_p0(0), coop_p1(0), 0u, lane, pixf_x, pixf_y);
-#ifdef GSR_STATS
-        { CO_T(tf2); CO_ADD(tw_c, tf1, tf2); }
-#endif
-        CO_BARRIER();
-        if (sh.finished[i & 1]) break;
-        live = sh.live[i & 1];
-    }
-    CO_STORE(1u);
-}
-
-__device__ __forceinline__ void coop_consumer(const RenderArgs& a, CoopShared& sh, const uint32_t tile, const uint32_t q,
-                                              const uint32_t lane, const uint2 range, const int total, const bool crossed0,
-                                              const uint32_t x0, const uint32_t y0)
-{
-    const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
-    const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
-    // A pixel that has terminated keeps its results in final_*, and its T becomes 0: c * alpha * 0 adds an exact +0 to its
-    // colour from then on, so the blend below needs no per-pixel masking; only the stop test looks at the live mask.
-    const size_t pix0 = (size_t)py * a.W + px, N0 = (size_t)a.W * a.H;
-    const float Ts = inside ? a.final_T[pix0] : -1.0f;       // phase one's state: negative = terminated there
-    float T = Ts > 0.f ? Ts : 0.f;
-    float final_T = -Ts;
-    f32x2 C01 = {0.f, 0.f};
-    float C2 = 0.f;
-    uint32_t lc = 0;                      // last contributor (positions grow along the list: a running maximum; exact while the pixel lives)
-    if (inside) {
-        C01 = f32x2{a.accum[pix0], a.accum[N0 + pix0]};
-        C2 = a.accum[2 * N0 + pix0];
-        lc = a.n_contrib[pix0];
-    }
-    uint32_t final_lc = lc, stop_at = 0;
-    bool crossed = crossed0;              // phase one already left its state at a slice boundary
-    uint64_t live = __ballot(Ts > 0.f);
-    bool finished = live == 0;
-    CO_DECL();
-    CO_BARRIER();   // the stager's prologue (batch 0)
-    for (int i = 0;; i++) {
-#ifdef GSR_STATS
-        CO_T(tc0); n_it++;
-#endif
-        if (i >= 1 && !finished) {
-            const uint32_t* d = sh.desc[(i - 1) & 3];
-            const uint32_t bs = d[0], marks = d[3];
-#ifdef GSR_STATS
-            n_x += (unsigned long long)d[1];
-#endif
-            const bool is_last = d[2] != 0;
-            const int cb = (i - 1) & 1;
-            // backward work items are slices of BWD_CHUNK list entries: leave the state at the boundaries this quadrant crosses
-            for (uint32_t k = marks & 0xFFFFu, e = k + (marks >> 16); k < e; k++) {
-                const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)k;
-                const bool dead = ((live >> lane) & 1ull) == 0;
-                a.ckpt[slot * 256 + q * 64 + lane] = make_float4(dead ? final_T : T, C01.x, C01.y, C2);
-                crossed = true;
-            }
-            if (d[1] != 0) {
-                const float* al = &sh.alpha[cb][0][lane][0];
-                const float* cr = &sh.crec[bs][0][0];
-                const uint32_t* hp = &sh.hitpos[cb][0][lane];
-                f32x2 ae = *(const f32x2*)(al);
-                uint32_t hh = *hp;
-                f32x4 rg = *(const f32x4*)(cr + 0);
-                f32x2 bb = *(const f32x2*)(cr + 4);
-                // one pair: blends (ae, rg, bb) = pair pr; returns false when the quadrant is finished
-                auto blend = [&](const f32x2 ae_, const uint32_t hh_, const f32x4 rg_, const f32x2 bb_, const int pr) -> bool {
-                    const float ae0 = ae_.x, ae1 = ae_.y;
-                    const float T1 = T * (1 - ae0), T2 = T1 * (1 - ae1);
-                    if ((__ballot(T2 < 0.0001f) & live) == 0) {
-                        const f32x2 rg0 = {rg_.x, rg_.y}, rg1 = {rg_.z, rg_.w};
-                        C01 += rg0 * ae0 * T;
-                        C2 += bb_.x * ae0 * T;
-                        C01 += rg1 * ae1 * T1;
-                        C2 += bb_.y * ae1 * T1;
-                        T = T2;
-                        lc = hh_ > lc ? hh_ : lc;
-                        return true;
-                    }
-                    // some live pixel stops inside this pair (see quadrant_walk for the case analysis)
-                    const uint32_t lc_now = lc;
-                    const uint2 pos = *(const uint2*)(&sh.crec[bs][pr][6]);
-                    const bool alive = ((live >> lane) & 1ull) != 0;
-                    const bool cnt0 = alive && ae0 != 0.f, cnt1 = alive && ae1 != 0.f;
-                    const bool s0 = cnt0 && (T1 < 0.0001f);
-                    const bool s1 = !s0 && cnt1 && (T2 < 0.0001f);
-                    const bool b0 = cnt0 && !s0, b1 = cnt1 && !s0 && !s1;
-                    const float be0 = b0 ? ae0 : 0.f, be1 = b1 ? ae1 : 0.f;
-                    const float U1 = T * (1 - be0), U2 = U1 * (1 - be1);
-                    const f32x2 rg0 = {rg_.x, rg_.y}, rg1 = {rg_.z, rg_.w};
-                    C01 += rg0 * be0 * T;
-                    C2 += bb_.x * be0 * T;
-                    C01 += rg1 * be1 * U1;
-                    C2 += bb_.y * be1 * U1;
-                    const bool stops = s0 || s1;
-                    final_T = stops ? U2 : final_T;
-                    final_lc = stops ? (b0 ? pos.x : lc_now) : final_lc;      // (b1 is false for a pixel that stops)
-                    stop_at = stops ? (s0 ? pos.x : pos.y) : stop_at;
-                    T = stops ? 0.f : U2;
-                    lc = hh_ > lc ? hh_ : lc;          // (of no consequence for the pixels that stopped: final_lc)
-                    live &= ~__ballot(stops);
-                    return live != 0;
-                };
-                // Pair p + 1 is read from LDS while pair p is blended; the loop body is written out twice with the two register
-                // sets swapped, so no register moves are needed to rotate them.
-#pragma unroll 1
-                for (int pr = 0; pr < COOP_BATCH; pr += 2) {
-                    const f32x2 ae_b = *(const f32x2*)(al + 128);
-                    const uint32_t hh_b = hp[64];
-                    const f32x4 rg_b = *(const f32x4*)(cr + 8);
-                    const f32x2 bb_b = *(const f32x2*)(cr + 12);
-                    if (!blend(ae, hh, rg, bb, pr)) break;
-                    al += 256; cr += 16; hp += 128;
-                    // (the pair after the last one of the batch is read as well: a valid address, never used)
-                    ae = *(const f32x2*)(al);
-                    hh = *hp;
-                    rg = *(const f32x4*)(cr + 0);
-                    bb = *(const f32x2*)(cr + 4);
-                    if (!blend(ae_b, hh_b, rg_b, bb_b, pr + 1)) break;
-                }
-            }
-            finished = live == 0 || is_last;
-        }
-        if (lane == 0) {
-            sh.live[i & 1] = live;
-            sh.finished[i & 1] = finished ? 1u : 0u;
-        }
-#ifdef GSR_STATS
-        { CO_T(tc1); CO_ADD(tw_a, tc0, tc1); }
-#endif
-        CO_BARRIER();
-        if (finished) break;
-    }
-#ifdef GSR_STATS
-    tw_b = tw0 & 0xFFFFFFFFull;                  // (consumer records: when the wave started and ended, 10-ns ticks)
-    tw_c = wall_clock64() & 0xFFFFFFFFull;
-#endif
-    CO_STORE(0u);
-
-    const bool done = ((live >> lane) & 1ull) == 0;
-    {
-        uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const uint32_t o = __shfl_xor(need, d, 64);
-            need = need > o ? need : o;
-        }
-        if (lane == 0 && need != 0) atomicMax(&a.tile_need[tile], need);
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
-        const float Tf = done ? final_T : T;
-        a.final_T[pix] = Tf;
-        a.n_contrib[pix] = done ? final_lc : lc;
-        a.out_color[pix] = C01.x + Tf * a.bg[0];
-        a.out_color[N + pix] = C01.y + Tf * a.bg[1];
-        a.out_color[2 * N + pix] = C2 + Tf * a.bg[2];
-        if (crossed) {
-            a.accum[pix] = C01.x;
-            a.accum[N + pix] = C01.y;
-            a.accum[2 * N + pix] = C2;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_render_forward_cont(RenderArgs a)
-{
-    __shared__ __attribute__((aligned(16))) CoopShared lds;
-    const uint32_t view = blockIdx.y;
-    a.ranges = at_view(a.ranges, a.iv_stride, view);
-    a.final_T = at_view(a.final_T, a.iv_stride, view);
-    a.n_contrib = at_view(a.n_contrib, a.iv_stride, view);
-    a.tile_need = at_view(a.tile_need, a.iv_stride, view);
-    a.accum = at_view(a.accum, a.iv_stride, view);
-    a.point_list = at_view(a.point_list, a.b_stride, view);
-    if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
-    a.splat = at_view(a.splat, a.g_stride, view);
-    a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
-    const uint32_t n_items = at_view(a.cont_count, a.iv_stride, view)[0];
-    const uint32_t* items = at_view(a.cont_items, a.iv_stride, view);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        if (it != blockIdx.x) __syncthreads();        // the previous item's LDS state is no longer read by anybody
-        const uint32_t item = items[2 * it], where = items[2 * it + 1];
-        const uint32_t tile = item & ((1u << BWD_TILE_BITS) - 1u), q = item >> BWD_TILE_BITS;
-        const int start = (int)(where & 0x7FFFFFFFu);
-        const uint2 range = a.ranges[tile];
-        const int total = (int)(range.y - range.x);
-        const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
-        const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
-        if (wave == 0) coop_consumer(a, lds, tile, q, lane, range, total, (where >> 31) != 0, x0, y0);
-        else if (wave == 1) coop_stager(a, lds, lane, range, total, start, x0, y0);
-        else coop_producer(a, lds, lane, wave - 1u, x0, y0);
-    }
-}
-
-// Batches of up to this many views render in two phases: with more views in one launch the chip is full of independent
-// quadrant waves and the deep walks of one view hide behind the bulk of the others.
-// GSR_COOP_MAX_VIEWS overrides (0 = never), GSR_COOP_CAP the entries phase one walks (a multiple of BWD_CHUNK, or of 64 for tests).
-static int coop_max_views()
-{
-    static const int v = [] {
-        const char* e = getenv("GSR_COOP_MAX_VIEWS");
-        return e ? atoi(e) : 2;
-    }();
-    return v;
-}
-static int coop_cap()
-{
-    static const int v = [] {
-        const char* e = getenv("GSR_COOP_CAP");
-        const int c = e ? atoi(e) : 256;
-        return c < 1 ? 1 : c;
-    }();
-    return v;
 }
 
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
@@ -1104,21 +525,11 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     a.num_tiles = T;
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
     a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr;
-    a.cap = 0; a.cont_items = nullptr; a.cont_count = nullptr;
     const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);
     if (X != nullptr && X->nx > 0) {
         a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out;
         if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
         else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
-    } else if (B.V <= coop_max_views()) {
-        a.cap = coop_cap();
-        a.cont_items = B.iv.cont_items;
-        a.cont_count = B.iv.bwd_count + 1;      // (a word of the per-frame cleared block)
-        hipLaunchKernelGGL(k_render_forward<0>, grid, dim3(64), 0, L.stream, a);
-        if (int e = check_launch(L, "render_forward")) return e;
-        int64_t wgs = 4ll * T;
-        if (wgs > 2048) wgs = 2048;
-        hipLaunchKernelGGL(k_render_forward_cont, dim3((unsigned)wgs, (unsigned)B.V), dim3(256), 0, L.stream, a);
     } else {
         hipLaunchKernelGGL(k_render_forward<0>, grid, dim3(64), 0, L.stream, a);
     }
