@@ -4,26 +4,33 @@
 
 Workload (BASELINE.json metric, configs[2]): synth-THuman-800K -- 800 000 synthetic Gaussians
 ("training" profile: opacity U(0.2,1), SH degree 1 in 13 rows) rendered at 1920x1080 from the reference's 12
-`circle` cameras, forward + backward through the public GaussianRasterizer API, loss = sum(img * G).
-A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered (one collective per submission) on
-rank 0 with RCCL (weak scaling).  All inputs are resident in HBM before the timed region.
-Frames are submitted --views-per-call (default 12, one turn of the circle) at a time through rasterize_views -- the C ABI's
-gsr_forward_batch / gsr_backward_batch: every kernel covers all views of the submission, nothing on the host waits for
-the device inside a frame, gradients of the shared cloud are summed over the views on the device -- with --streams (default
-2) submissions in flight on their own HIP streams.  K steps that are not a multiple of the batch end with a smaller batch.
-The per-stage timings and the single-stream rate come from a single-stream pass right after the timed region; the same
-frames through the reference's per-view call (one GaussianRasterizer call per view) are timed next to it
-(`per_view_api_frames_per_s`).
+`circle` cameras, forward + backward through the public API, loss = sum(img * G).
+A step = one frame (one camera view) per rank; views are sharded round-robin over ranks, frames are gathered on rank 0 with
+RCCL, one collective per submission, on a stream of its own (weak scaling).  All inputs are resident in HBM before the timed region.
+
+HEADLINE call shape (`config.workload` says so): frames are submitted --views-per-call (default 12, one turn of the circle) at a
+time through rasterize_views -- the C ABI's gsr_forward_batch / gsr_backward_batch: every kernel covers all views of the
+submission, nothing on the host waits for the device inside a frame, gradients of the shared cloud are summed over the views on
+the device -- with --streams (default 2) submissions in flight on their own HIP streams.  K steps that are not a multiple of the
+batch end with a smaller batch.  The timed region is `--repeats` (default 5) blocks of exactly K steps, every block bracketed by
+barrier + synchronize; `value` / `ms_per_step` are the MEDIAN block (max over ranks per block), all blocks are listed.
+
+Beside the headline the line carries (rank 0, measured right after the timed region, never inside it):
+  kernels_ms / roofline -- a single-stream pass with hipEvents around every stage on the launch stream: the dominant kernel's
+                  ALGORITHMIC bytes / its measured duration against the 8 TB/s HBM peak (and the ~6.3 TB/s a copy reaches), its
+                  VALU issue rate, and -- only if profiles/pmc_traffic.json was taken on exactly this workload and call shape -- the
+                  counter traffic and the profile's own duration of that kernel (`profile_avg_ms`, `frac_profile`,
+                  `live_vs_profile`); `traffic` is null otherwise;
+  drop_in_api  -- the same frames through the reference's call pattern (one GaussianRasterizer call per view,
+                  /root/reference/simple_raw_render.py:259-278): frames/s on one and on four streams and its own per-stage times;
+  forward_only -- inference frames/s of both call shapes;
+  rgb_time_equiv -- the reference's own timing hook (`rgb time`, simple_raw_render.py:433-456): 12 views x 1024^2 (512^2 camera,
+                  super-sample 2), the SH colour pass, INCLUDING per-view settings glue and the bilinear down-filter;
+  cpu_baseline -- the plain-C oracle (OpenMP) on frames of the same workload (N=1): 1 warm-up + median of 5 frames on all host
+                  cores, plus a 1-core figure from one frame.
 
 `--gpus N` with N > 1 and no torch.distributed.run environment re-launches itself under torch.distributed.run with N ranks
-(one per GPU, RCCL); it refuses loudly when the box has fewer than N GPUs.  The timed region is `--repeats` (default 5)
-blocks of exactly K steps each, every block bracketed by barrier + synchronize; `value` / `ms_per_step` are the MEDIAN block
-(max over ranks per block), all blocks are listed in `ms_per_step_blocks`.
-
-Prints ONE JSON line on rank 0 with the throughput plus
-  roofline     -- the dominant kernel's algorithmic bytes / its measured duration (hipEvents on the launch stream)
-  cpu_baseline -- the plain-C oracle (OpenMP) on frames of the same workload (rank 0, N=1): 1 warm-up + median of 5 frames on
-                  all host cores, plus a 1-core figure from one frame.
+(one per GPU, RCCL); it refuses loudly when the box has fewer than N GPUs.
 """
 import argparse
 import json
@@ -45,8 +52,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
-VALU_PEAK_GWIPS = 1228.9  # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches (same guide)
+VALU_PEAK_GWIPS = 1228.9     # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
+
+STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>", "preprocess": "k_preprocess<1>",
+                "preprocess_backward": "k_preprocess_backward<1>", "duplicate": "k_duplicate<unsigned short>"}
 
 
 def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
@@ -83,12 +94,14 @@ def main():
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "12")),
                     help="frames submitted per rasterizer call: 1 = the reference's per-view GaussianRasterizer call; V > 1 = "
                          "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission")
-    ap.add_argument("--no-per-view", action="store_true", help="skip the per-view-API comparison pass")
+    ap.add_argument("--no-per-view", action="store_true", help="skip the drop-in-API / forward-only / rgb-time side measurements")
+    ap.add_argument("--no-stage-events", action="store_true",
+                    help="no per-stage hipEvents anywhere (for timeline traces: an event pair costs ~10 us of bubble per stage)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the all-core CPU baseline (after 1 warm-up)")
     ap.add_argument("--no-cpu-1core", action="store_true", help="skip the 1-core CPU figure (about a minute of CPU time)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "2")),
-                    help="host threads per rank, each rendering whole frames on its own HIP stream (views are independent)")
+                    help="host threads per rank, each rendering whole submissions on its own HIP stream (views are independent)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 lets several ranks share one GPU to exercise the multi-rank control flow "
                          "(frames then travel through host memory; not a performance mode)")
@@ -146,15 +159,15 @@ def main():
     rasterizers = [GaussianRasterizer(s) for s in settings]
 
     grad = not args.forward_only
-    leaf = lambda a: torch.from_numpy(a).to(dev).requires_grad_(grad)  # noqa: E731
 
-    def make_leaves():
+    def make_leaves(with_grad):
+        leaf = lambda a: torch.from_numpy(a).to(dev).requires_grad_(with_grad)  # noqa: E731
         m3 = leaf(g["means3D"])
-        return dict(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=grad), shs=leaf(g["shs"]),
+        return dict(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=with_grad), shs=leaf(g["shs"]),
                     opacities=leaf(g["opacities"]), scales=leaf(g["scales"]), rotations=leaf(g["rotations"]))
 
     # one set of leaf tensors per host thread (their .grad is written by that thread's backward only)
-    leafsets = [make_leaves() for _ in range(max(4, args.streams))]
+    leafsets = [make_leaves(grad) for _ in range(max(4, args.streams))]
     means3D, shs, opac = leafsets[0]["means3D"], leafsets[0]["shs"], leafsets[0]["opacities"]
     scales, rots = leafsets[0]["scales"], leafsets[0]["rotations"]
     G = torch.from_numpy(np.random.default_rng(123).uniform(-1, 1, (3, H, W)).astype(np.float32)).to(dev)
@@ -163,14 +176,16 @@ def main():
     # for the point-to-point xGMI links than a gather per frame
     gather_bufs = [torch.empty((VPC, 3, H, W), device="cpu" if host_collectives else dev) for _ in range(world)] \
         if (use_dist and rank == 0) else None
-
     do_gather = use_dist and not args.no_gather
+    # the gather has a stream of its own: it only waits for the submission it ships, the next submission's kernels run beside it
+    gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
+    gather_events = []      # (start, end) on the gather stream, one pair per submission of the timed region
 
-    def render(i, tslot=0):
+    def render(i, tslot=0, with_grad=True, vpc_views=None):
         """Forward (+ backward) of global step i on the calling thread's current stream; returns the frame."""
         v = (i * world + rank) % n_views
         L = leafsets[tslot]
-        if grad:
+        if with_grad:
             img, _ = rasterizers[v](**L)
             (img * G).sum().backward()
             for t in L.values():
@@ -180,13 +195,13 @@ def main():
             img, _ = rasterizers[v](**L)
         return img
 
-    def render_many(i, n, tslot=0):
+    def render_many(i, n, tslot=0, with_grad=True):
         """Global steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
         if n == 1:
-            return render(i, tslot)[None]
+            return render(i, tslot, with_grad)[None]
         L = leafsets[tslot]
         sts = [settings[((i + k) * world + rank) % n_views] for k in range(n)]
-        if grad:
+        if with_grad:
             imgs, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], sts, shs=L["shs"], scales=L["scales"],
                                       rotations=L["rotations"])
             (imgs * G).sum().backward()
@@ -198,11 +213,23 @@ def main():
                                       rotations=L["rotations"])
         return imgs
 
+    timing_gather = [False]
+
     def gather(imgs):
-        """imgs [n,3,H,W], n <= VPC: this rank's frames of one submission -> rank 0."""
+        """imgs [n,3,H,W], n <= VPC: this rank's frames of one submission -> rank 0, on the gather stream."""
         n = imgs.shape[0]
-        dist.gather(imgs.cpu() if host_collectives else imgs.contiguous(),
-                    gather_list=[b[:n] for b in gather_bufs] if rank == 0 else None, dst=0)
+        cur = torch.cuda.current_stream(dev)
+        gather_stream.wait_stream(cur)               # run_frames_pipelined made `cur` wait for the submission's last kernel
+        with torch.cuda.stream(gather_stream):
+            if timing_gather[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(gather_stream)
+            src = imgs.cpu() if host_collectives else imgs.contiguous()
+            src.record_stream(gather_stream) if src.is_cuda else None
+            dist.gather(src, gather_list=[b[:n] for b in gather_bufs] if rank == 0 else None, dst=0)
+            if timing_gather[0]:
+                e1.record(gather_stream)
+                gather_events.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -210,19 +237,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(first, count, streams=None, vpc=None):
+    def run_steps(first, count, streams=None, vpc=None, with_grad=None, gather_on=None):
         """`count` steps from global step `first`, submitted --views-per-call at a time, --streams submissions in flight
         (pcrender.multiview.run_frames_pipelined); the frame gather is issued by this thread only, in step order, so every
         rank enqueues collectives identically."""
+        wg = grad if with_grad is None else with_grad
         ch = []
         i = first
         while i < first + count:
             n = min(VPC if vpc is None else vpc, first + count - i)
             ch.append((i, n))
             i += n
-        multiview.run_frames_pipelined(lambda ci, slot: render_many(ch[ci][0], ch[ci][1], slot), 0, len(ch),
+        go = do_gather if gather_on is None else gather_on
+        multiview.run_frames_pipelined(lambda ci, slot: render_many(ch[ci][0], ch[ci][1], slot, wg), 0, len(ch),
                                        args.streams if streams is None else streams,
-                                       on_frame=(lambda ci, imgs: gather(imgs)) if do_gather else None, device=dev)
+                                       on_frame=(lambda ci, imgs: gather(imgs)) if go else None, device=dev)
+
+    def timed(count, **kw):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(warm, count, gather_on=False, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1
+
+    def stage_pass(count, **kw):
+        """single-stream pass with hipEvents around every stage; returns ({stage: mean ms per launch}, wall seconds)"""
+        torch.cuda.synchronize()
+        _native.set_profiling(True)
+        t1 = time.perf_counter()
+        run_steps(warm, count, streams=1, gather_on=False, **kw)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        ms = {}
+        for name, t in _native.get_profile():
+            ms.setdefault(name, []).append(t)
+        _native.set_profiling(False)
+        return {k: float(np.mean(v)) for k, v in ms.items()}, d1
 
     # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
     # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing
@@ -230,49 +280,69 @@ def main():
     run_steps(0, max(warm, VPC * max(1, args.streams) * 2), streams=1)      # primes the caller's stream and allocator pool
     run_steps(0, max(warm, VPC * max(1, args.streams) * 2))
     fence()
-    _native.set_profiling(rank == 0 and args.streams <= 1)
     block_dt = []
     nxt = warm
+    timing_gather[0] = True
     for _ in range(max(1, args.repeats)):
         t0 = time.perf_counter()
         run_steps(nxt, args.steps)
         fence()
         block_dt.append(time.perf_counter() - t0)
         nxt += args.steps
-    prof = _native.get_profile() if rank == 0 else []
-    _native.set_profiling(False)
-    kernel_timing = "hipEvents on the launch stream over the timed region"
-    single = None
-    if rank == 0 and args.streams > 1:
-        # with several streams in flight the per-stage events overlap; time the stages in a single-stream pass instead
+    timing_gather[0] = False
+    gather_ms = [float(a.elapsed_time(b)) for a, b in gather_events] if gather_events else None
+
+    avg_ms, single = {}, None
+    per_view = drop_in = fwd_only = rgb_time = None
+    if rank == 0 and not args.no_stage_events:
         n1 = max(min(args.steps, 24), VPC)
-        torch.cuda.synchronize()
-        _native.set_profiling(True)
-        t1 = time.perf_counter()
-        _gather_on, do_gather = do_gather, False     # this pass runs on rank 0 only, a collective would never complete
-        run_steps(warm, n1, streams=1)
-        do_gather = _gather_on
-        torch.cuda.synchronize()
-        d1 = time.perf_counter() - t1
-        prof = _native.get_profile()
-        _native.set_profiling(False)
-        single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1}
-        kernel_timing = "hipEvents, single-stream pass of %d frames right after the timed region" % n1
-    per_view = None
-    if rank == 0 and VPC > 1 and not args.no_per_view:
-        # the same frames through the reference's per-view call (GaussianRasterizer, one view per submission), for comparison
-        _gather_on, do_gather = do_gather, False
-        per_view = {}
+        avg_ms, d1 = stage_pass(n1)
+        single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1,
+                  "note": "one submission in flight, hipEvents around every stage (each pair costs ~10 us of bubble)"}
+    if rank == 0 and not args.no_per_view and not args.no_stage_events:
+        # ---- the drop-in API: the reference's call pattern, one GaussianRasterizer call per view (simple_raw_render.py:259-278)
+        drop_in = {"call": "GaussianRasterizer(settings_v)(means3D, means2D, opacities, shs=, scales=, rotations=) per view + "
+                           "loss.backward() per view" if grad else "GaussianRasterizer(...) per view under no_grad",
+                   "frames_per_s": {}}
         for name, st in (("one_stream", 1), ("four_streams", 4)):
             if st > len(leafsets):
                 continue
-            run_steps(warm, 12, streams=st, vpc=1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run_steps(warm, 48, streams=st, vpc=1)
-            torch.cuda.synchronize()
-            per_view[name] = round(48 / (time.perf_counter() - t1), 1)
-        do_gather = _gather_on
+            run_steps(warm, 12, streams=st, vpc=1, gather_on=False)
+            drop_in["frames_per_s"][name] = round(48 / timed(48, streams=st, vpc=1), 1)
+        pv_ms, _ = stage_pass(24, vpc=1)
+        drop_in["kernels_ms_per_frame"] = {k: round(v, 4) for k, v in pv_ms.items()}
+        drop_in["kernel_sum_ms_per_frame"] = round(sum(pv_ms.values()), 4)
+        per_view = drop_in["frames_per_s"]
+        # ---- inference (forward only), both call shapes
+        if grad:
+            run_steps(warm, 2 * VPC, with_grad=False, gather_on=False)
+            fwd_only = {"views_per_call_%d_frames_per_s" % VPC: round(4 * VPC / timed(4 * VPC, with_grad=False), 1),
+                        "per_view_call_frames_per_s": round(48 / timed(48, streams=1, vpc=1, with_grad=False), 1)}
+        # ---- the reference's own timing hook: `rgb time` = 12 views x (512^2 camera, super-sample 2 -> 1024^2 raster), SH pass,
+        # per-view settings construction and the bilinear down-filter INSIDE the timed region (simple_raw_render.py:433-456)
+        try:
+            from pcrender import raster_passes as rp
+            Hs = camera.circle_path(12, 0, 3, [90, 0]).unsqueeze(0)
+            sf = float(cloud["scale_factor"])
+            radius = float(np.sqrt(3) / sf * 6)
+            dec_s = (scales.detach() / radius).contiguous()
+            with torch.no_grad():
+                def rgb_pass(batch_views):
+                    return rp.rasterize_views([means3D.detach()], [opac.detach()], [dec_s], [rots.detach()], Hs, 512, 512, 45.0,
+                                              torch.ones(3), sf, shs_list=[shs.detach()], sh_degree=D, batch_views=batch_views)
+                rgb_time = {"what": "12 circle views, 512x512 camera x super-sample 2 (1024x1024 raster), SH colour pass, per-view "
+                                    "settings glue + bilinear down-filter included; this workload's cloud", "ms_per_12_views": {}}
+                for name, bv in (("literal_per_view_calls", False), ("views_in_one_call", True)):
+                    for _ in range(2):
+                        rgb_pass(bv)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        rgb_pass(bv)
+                    torch.cuda.synchronize()
+                    rgb_time["ms_per_12_views"][name] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
+            rgb_time = {"error": repr(ex)}
     if use_dist:
         t = torch.tensor(block_dt, device="cpu" if host_collectives else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,8 +362,8 @@ def main():
                 cp = torch.stack([settings[v].campos.reshape(3) for v in vs])
                 s0 = settings[vs[0]]
                 counts, _, radii, geom, binning, img = _native.rasterize_gaussians_batch(
-                    s0.bg, means3D, torch.empty(0), opac, scales, rots, 1.0, torch.empty(0), vm, pm, s0.tanfovx, s0.tanfovy, H, W,
-                    shs, D, cp, False, False, need_backward=True)
+                    s0.bg, means3D.detach(), torch.empty(0), opac.detach(), scales.detach(), rots.detach(), 1.0, torch.empty(0), vm, pm,
+                    s0.tanfovx, s0.tanfovy, H, W, shs.detach(), D, cp, False, False, need_backward=True)
                 for k in range(len(vs)):
                     R = counts[k]
                     need = _native.query("TILE_NEED", P, W, H, R, geom, binning, img, view=k, n_views=len(vs)).long()
@@ -308,40 +378,54 @@ def main():
         tile_bits = int(T).bit_length()
         bytes_per = algorithmic_bytes(P, stats["V"], stats["R"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
                                       (tile_bits + 7) // 8)
-        ms = {}
-        for name, t in prof:
-            ms.setdefault(name, []).append(t)
-        avg_ms = {k: float(np.mean(v)) for k, v in ms.items()}
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
         roofline = None
-        traffic = None
-        valu = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE, KiB -> B)
+        # HBM bytes / VALU instructions / kernel duration per launch from the committed rocprofv3 passes -- only if they were taken
+        # on THIS workload and call shape (scripts/profile_gpu.sh writes the key); anything else would be a number about
+        # another run
+        pmc, pmc_why = None, None
+        key = {"workload": args.workload, "points": P, "width": W, "height": H, "views_per_launch": VPC, "profile": args.profile,
+               "forward_only": bool(args.forward_only)}
+        try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            kname = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>"}.get(dom, dom)
-            scale = VPC / float(pmc.get("views_per_launch", 1))      # the profile's launches covered that many views each
-            traffic = pmc.get("bytes_per_launch", {}).get(kname)
-            valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
-            traffic = None if traffic is None else int(traffic * scale)
-            valu = None if valu is None else valu * scale
-        except (OSError, ValueError):
-            traffic = None
+            if pmc.get("key") != key:
+                pmc_why = "profiles/pmc_traffic.json was taken on %s, this run is %s" % (json.dumps(pmc.get("key")), json.dumps(key))
+                pmc = None
+        except (OSError, ValueError) as ex:
+            pmc_why = "profiles/pmc_traffic.json: %r" % (ex,)
         if dom is not None:
             achieved = bytes_per[dom] * VPC / (avg_ms[dom] * 1e-3) / 1e9     # a launch covers VPC views
+            kname = STAGE_KERNEL.get(dom, dom)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBS, 5),
                         "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(avg_ms[dom], 4),
                         "views_per_launch": VPC,
-                        "traffic_source": "(2*FETCH_SIZE + WRITE_SIZE) per launch from the committed rocprofv3 PMC passes of this "
-                                          "command (profiles/pmc_traffic.json, scripts/profile_gpu.sh); avg_ms is measured live"}
-            if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
-                rate = valu / (avg_ms[dom] * 1e-3)
-                roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
-                                    "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
-                                    "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json"}
+                        "note": "the render kernels are VALU-bound by two orders of magnitude of arithmetic intensity (SURVEY 8d): "
+                                "the fraction of the HBM roofline is structurally small; see `valu`"}
+            if pmc is not None:
+                roofline["traffic"] = pmc.get("bytes_per_launch", {}).get(kname)
+                roofline["traffic_source"] = ("(FETCH_SIZE x %s + WRITE_SIZE) per launch, rocprofv3 PMC passes of this command in the "
+                                              "same lease as the kernel trace (profiles/pmc_traffic.json; the FETCH factor is the one "
+                                              "profiles/r03_fetch_calibration.txt measures for this kernel's access pattern)"
+                                              % pmc.get("fetch_factor", {}).get(kname, pmc.get("fetch_factor", {}).get("default", 2)))
+                pa = pmc.get("avg_us", {}).get(kname)
+                if pa:
+                    roofline["profile_avg_ms"] = round(pa / 1e3, 4)
+                    roofline["frac_profile"] = round(bytes_per[dom] * VPC / (pa * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                    rel = avg_ms[dom] / (pa / 1e3)
+                    roofline["live_vs_profile"] = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
+                valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
+                if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
+                    rate = valu / (avg_ms[dom] * 1e-3)
+                    roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
+                                        "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
+                                        "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json; duration measured live"}
+            else:
+                roofline["traffic_source"] = "null: " + pmc_why
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
-        frame_gpu_ms = sum(avg_ms.values()) / VPC
+        frame_gpu_ms = sum(avg_ms.values()) / VPC if avg_ms else 0.0
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -367,13 +451,18 @@ def main():
             cdt = float(np.median(times))
             what = "forward+backward" if grad else "forward"
             cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "circle view 0 of the same workload, %s, plain-C oracle with OpenMP: 1 warm-up + median of %d frames "
+                   "sample": "circle view 0 of the same workload, %s, plain-C oracle with OpenMP (parallel per-Gaussian stages, "
+                             "parallel stable radix sort, per-thread gradient buffers): 1 warm-up + median of %d frames "
                              "(min %.3f s, max %.3f s)" % (what, len(times), times[0], times[-1])}
             if not args.no_cpu_1core:
                 c1 = cpu_frame(1)
                 cpu["one_core"] = {"value": round(1.0 / c1, 5), "unit": "frames/s", "cores": 1,
                                    "sample": "1 frame of the same view, %s, single thread (no warm-up: %.1f s of CPU work)" % (what, c1)}
+                cpu["speedup_over_one_core"] = round(c1 / cdt, 2)
 
+        shape = ("%d views per rasterize_views call (C ABI gsr_forward_batch%s), %d call%s in flight per rank" % (
+            VPC, " / gsr_backward_batch" if grad else "", args.streams, "s" if args.streams != 1 else "")) if VPC > 1 else (
+            "one GaussianRasterizer call per view (the reference's call pattern), %d in flight per rank" % args.streams)
         out = {
             "metric": "rendered frames/sec at 1080p (fwd+bwd), THuman-800K" if (grad and (W, H) == (1920, 1080)) else
                       "rendered frames/sec %dx%d (%s)" % (W, H, "fwd+bwd" if grad else "fwd"),
@@ -381,20 +470,33 @@ def main():
             "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in block_dt],
             "warmup": args.warmup, "warmup_effective": 2 * max(warm, VPC * max(1, args.streams) * 2), "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d), view-sharded%s" % (
-                args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M,
-                " + RCCL frame gather" if do_gather else ""),
+            "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d); %s; view-sharded%s" % (
+                args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M, shape,
+                " + RCCL frame gather on its own stream" if do_gather else ""),
+                "call_shape": {"views_per_call": VPC, "calls_in_flight": args.streams,
+                               "entry_point": "rasterize_views" if VPC > 1 else "GaussianRasterizer.forward"},
                 "points": P, "num_rendered_avg": int(stats["R"]), "visible_avg": int(stats["V"]),
                 "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()}, "kernel_timing": kernel_timing,
+            "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
+            "kernel_timing": "hipEvents on the launch stream, single-stream pass right after the timed region",
             "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},
             "streams_per_rank": args.streams, "single_stream": single,
-            "per_view_api_frames_per_s": per_view,
+            "drop_in_api": drop_in, "per_view_api_frames_per_s": per_view,
+            "forward_only": fwd_only, "rgb_time_equiv": rgb_time,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
-                          "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None},
+                          "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None,
+                          "frac_of_8000": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_gpu_ms else None,
+                          "frac_of_6300": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4) if frame_gpu_ms else None},
         }
+        if use_dist:
+            out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                  "gather": None if not gather_ms else {
+                                      "collectives": len(gather_ms), "bytes_into_rank0_per_collective": int((world - 1) * VPC * 3 * H * W * 4),
+                                      "ms_mean": round(float(np.mean(gather_ms)), 4), "ms_max": round(float(np.max(gather_ms)), 4),
+                                      "note": "hipEvents on the gather stream around each dist.gather (includes waiting for the peers' "
+                                              "submissions); the gather overlaps the next submission's kernels"}}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

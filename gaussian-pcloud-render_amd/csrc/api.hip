@@ -105,12 +105,16 @@ struct ProfScope {
     }
 };
 
-// ---- per-thread pinned landing zone for the counter read-back ------------------------------------------
+// ---- per-thread landing zone for the counter read-back ----------------------------------------------------
+// Host memory mapped into the device: the pair-emission kernel stores the per-view counters there itself, and the host
+// reads them after an event recorded behind that kernel.  No copy command (on this runtime a small device->host copy is a
+// blit kernel plus two ~10 us bubbles in the stream).
 constexpr int MAX_VIEWS = 256;
 // One per (host thread, device): an event belongs to the device that was current when it was created, so a thread that
 // renders on several GPUs needs one landing zone for each.
 struct HostLanding {
-    uint64_t* pinned = nullptr;   // [MAX_VIEWS][4]: num_rendered, trap flag, stall flag, -
+    uint64_t* pinned = nullptr;   // [MAX_VIEWS][4]: num_rendered, trap flag, stall flag, -   (host address)
+    uint64_t* mapped = nullptr;   // the same memory as the device sees it
     hipEvent_t ev = nullptr;
 };
 static thread_local std::map<int, HostLanding> t_lands;
@@ -120,7 +124,8 @@ static int landing(HostLanding** out)
     if (hipGetDevice(&dev) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] hipGetDevice: %s", hipGetErrorString(hipGetLastError()));
     HostLanding& h = t_lands[dev];
     if (!h.pinned) {
-        if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h.mapped, h.pinned, 0) != hipSuccess ||
             hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
             h.pinned = nullptr;
             return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
@@ -252,16 +257,16 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
             // 4 passes: the ids in depth order are back in buffer 0
         }
     }
+    // the emission kernel leaves the counters of every view in mapped host memory; the event behind it is waited for only
+    // after the rest of the frame has been enqueued
+    memset(t_land.pinned, 0, (size_t)V * 4 * sizeof(uint64_t));
     {
         ProfScope ps("duplicate", L.stream);
-        if (int e = launch_duplicate(L, p->P, B, gridx, key16)) return e;
+        if (int e = launch_duplicate(L, p->P, B, gridx, key16, t_land.mapped)) return e;
     }
-    // counters of every view -> pinned host memory; waited for only after the rest of the frame has been enqueued
     {
-        hipError_t e = V == 1 ? hipMemcpyAsync(t_land.pinned, B.g.counters, 32, hipMemcpyDeviceToHost, L.stream)
-                              : hipMemcpy2DAsync(t_land.pinned, 32, B.g.counters, B.g_stride, 32, (size_t)V, hipMemcpyDeviceToHost, L.stream);
         g_d2h_count++;
-        if (e == hipSuccess) e = hipEventRecord(t_land.ev, L.stream);
+        const hipError_t e = hipEventRecord(t_land.ev, L.stream);
         if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
     }
     if (mode != 2) {

@@ -68,6 +68,7 @@ struct DupArgs {
     uint32_t* vals;
     size_t b_stride;
     int64_t cap;
+    uint64_t* host_land;             // [V][4] host memory mapped into the device: num_rendered, trap flag, stall flag, - (api.hip)
 };
 
 template <typename KeyT>
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
                 v[k] = agent_load(&status[b0 + k * DUP_THREADS]);
                 if (v[k] == 0 && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
                     at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
+                    a.host_land[4 * view + CNT_STALL] = 1;
                     v[k] = 1;
                 }
             }
@@ -175,7 +177,15 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     if (threadIdx.x == 0) {
         const uint64_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         s_base = base;
-        if (blk == nblk - 1) at_view(a.counters, a.g_stride, view)[CNT_NUM_RENDERED] = base + block_total;
+        if (blk == nblk - 1) {
+            // the frame's pair count: for the kernels that follow (device memory) and for the host, which reads it from mapped
+            // memory once this kernel has completed -- no copy command in the stream
+            uint64_t* cnt = at_view(a.counters, a.g_stride, view);
+            cnt[CNT_NUM_RENDERED] = base + block_total;
+            a.host_land[4 * view + CNT_NUM_RENDERED] = base + block_total;
+            a.host_land[4 * view + CNT_TRAP] = cnt[CNT_TRAP];
+            __threadfence_system();
+        }
     }
     __syncthreads();
     DUP_T(t3);
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
 #endif
 }
 
-int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16)
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land)
 {
     DupArgs a;
     a.P = P;
@@ -245,6 +255,7 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     a.vals = B.b.val[0];
     a.b_stride = B.b_stride;
     a.cap = B.b.key[0] ? B.b.cap : 0;
+    a.host_land = host_land;
     const dim3 grid((unsigned)div_up(P, DUP_BLOCK), B.V);
     if (key16)
         hipLaunchKernelGGL(k_duplicate<uint16_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);

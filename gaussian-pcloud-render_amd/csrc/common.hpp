@@ -270,7 +270,7 @@ struct SortJob {
 int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16 = false);
 inline bool tile_keys16(int T) { return T <= 65536; }
 // binning.hip
-int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16);
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land);
 int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16);
 int launch_tile_order(const Launch& L, const Batch& B, int T);
 int launch_bwd_items(const Launch& L, const Batch& B, int T, int P);

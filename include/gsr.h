@@ -196,9 +196,10 @@ int gsr_get_profile(const char** names, float* ms, int cap);
  * Allocates its own small buffers; not part of the hot path.  0 = pass. */
 int gsr_selftest(gsr_stream_t stream);
 
-/* Number of device->host read-backs the library has issued in this process: exactly one per forward call (the 32-byte
- * per-view counter block: num_rendered, trap and stall flags), none per backward.  For tests that guard the call path
- * against host stalls. */
+/* Number of device->host read-backs the library has made in this process: exactly one per forward call -- the 32-byte
+ * per-view counter block (num_rendered, trap and stall flags), which the pair-emission kernel stores into mapped host
+ * memory and the host reads after ONE event wait, once the whole frame is enqueued -- and none per backward.  There is no
+ * copy command in the stream.  For tests that guard the call path against host stalls. */
 long long gsr_d2h_count(void);
 
 const char* gsr_last_error(void);

@@ -1,22 +1,49 @@
 """Copy the judged artefacts of a scripts/profile_gpu.sh run from gpurun_out/prof_<tag>/ into profiles/ and rebuild
-profiles/pmc_traffic.json (HBM-side bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE passes).
-usage: python scripts/update_profiles.py [tag [views_per_launch]]"""
+profiles/pmc_traffic.json: per kernel and per launch, the HBM-side bytes from the FETCH_SIZE / WRITE_SIZE passes, the VALU
+instruction count, and the kernel's average duration in the kernel trace OF THE SAME LEASE, keyed by the workload and call
+shape of the profiled command (bench.py prints `traffic` only for a run with the same key).
+usage: python scripts/update_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-views_per_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 12     # bench.py --views-per-call of the profiled command
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, "%s_bench_rocprofv3_summary.txt" % tag))
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "%s_bench_kernel_stats.csv" % tag))
+if os.path.exists(os.path.join(src, "fetch_calibration.txt")):
+    shutil.copy(os.path.join(src, "fetch_calibration.txt"), os.path.join(dst, "%s_fetch_calibration.txt" % tag))
+bench = json.loads([l for l in open(os.path.join(src, "bench.json")).read().splitlines() if l.startswith("{")][-1])
+json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
+wl = bench["config"]["workload"]
+W, H = [int(x) for x in wl.split()[1].split("x")]
+key = {"workload": wl.split()[0], "points": bench["config"]["points"], "width": W, "height": H,
+       "views_per_launch": bench["views_per_call"], "profile": "training" if "training profile" in wl else "inference",
+       "forward_only": "fwd+bwd" not in wl}
 
 
 def short(n):
     return n.split("(")[0].replace("gsr::", "").replace("void ", "")
 
+
+# FETCH_SIZE factor per access pattern, from the calibration probe of the same lease (bytes of the 64-B lines touched /
+# (FETCH_SIZE x 1024)): wide streaming kernels 2.0, the record gathers of the render kernels and the pair emission by k_gather*
+factor = {"default": 2.0}
+cal = os.path.join(src, "fetch_calibration.txt")
+if os.path.exists(cal):
+    for l in open(cal):
+        p = l.split()
+        if len(p) >= 9 and p[0] in ("k_stream16", "k_gather16", "k_gather36") and float(p[3]) > 0:
+            factor["_" + p[0]] = round(float(p[2]) / (float(p[3]) * 1024.0), 3)      # line bytes per counted byte
+    if "_k_stream16" in factor:
+        factor["default"] = factor["_k_stream16"]
+    for k in ("k_render_backward", "k_render_forward<0>"):
+        if "_k_gather36" in factor:
+            factor[k] = factor["_k_gather36"]
+    if "_k_gather16" in factor:
+        factor["k_duplicate<unsigned short>"] = factor["_k_gather16"]
 
 raw = collections.defaultdict(dict)
 for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
@@ -29,15 +56,24 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             acc[k] += float(r["Counter_Value"]); launches[k].add(r["Dispatch_Id"])
     for k in acc:
         raw[k][counter + "_KiB"] = acc[k] / max(len(launches[k]), 1)
+avg_us = {}
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        if k.startswith("k_"):
+            avg_us[k] = round(float(r["AverageNs"]) / 1e3, 3)
 out = {
-    "views_per_launch": views_per_launch,
-    "source": "profiles/%s_bench_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --streams 1)" % tag,
-    "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; x2 is the gfx950 FETCH_SIZE half-count correction of "
-               "MI355X_MICROARCH.md (calibrated there for wide coalesced reads; the render kernels' 16-B gathers are not "
-               "separately calibrated, so this is an upper bound for them); FETCH_SIZE counts fabric requests, "
-               "Infinity-Cache hits included",
-    "bytes_per_launch": {k: int((2 * v.get("FETCH_SIZE_KiB", 0.0) + v.get("WRITE_SIZE_KiB", 0.0)) * 1024) for k, v in raw.items()
-                         if k.startswith("k_")},
+    "key": key,
+    "source": "profiles/%s_bench_rocprofv3_summary.txt: rocprofv3 kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes of "
+              "`bench.py --streams 1` and the bench line profiles/%s_bench_line.json, all in one gpurun lease" % (tag, tag),
+    "formula": "(fetch_factor x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch; fetch_factor from profiles/%s_fetch_calibration.txt "
+               "(same lease): 64-B lines touched per counted byte for the kernel's access pattern (wide streaming read: the gfx950 "
+               "half count of MI355X_MICROARCH.md; 36-B-of-a-line record gathers for the render kernels); FETCH_SIZE counts fabric "
+               "requests, Infinity-Cache hits included" % tag,
+    "fetch_factor": factor,
+    "bytes_per_launch": {k: int((factor.get(k, factor["default"]) * v.get("FETCH_SIZE_KiB", 0.0) + v.get("WRITE_SIZE_KiB", 0.0)) * 1024)
+                         for k, v in raw.items() if k.startswith("k_")},
+    "avg_us": avg_us,
     "raw": {k: v for k, v in raw.items() if k.startswith("k_")},
 }
 sq = collections.defaultdict(lambda: collections.defaultdict(float)); sql = collections.defaultdict(set)
@@ -48,5 +84,6 @@ for f in glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"),
             sq[k][r["Counter_Name"]] += float(r["Counter_Value"]); sql[k].add(r["Dispatch_Id"])
 out["valu_wave_instructions_per_launch"] = {k: int(v["SQ_INSTS_VALU"] / max(len(sql[k]), 1)) for k, v in sq.items() if "SQ_INSTS_VALU" in v}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: out[k] for k in ("key", "fetch_factor", "avg_us")}, indent=1, sort_keys=True))
 print(json.dumps(out["bytes_per_launch"], indent=1, sort_keys=True))
 print(out["valu_wave_instructions_per_launch"])
