@@ -230,19 +230,25 @@ def _stack_views(settings_list, device):
                 not _same_background(s.bg, s0.bg):
             raise Exception("rasterize_views: the views of a batch must share image size, tan(fov), background, scale "
                             "modifier, SH degree and the prefiltered flag")
+    _C._require_hip(device)
     key = (device.type, device.index) + tuple(k for s in settings_list for t in (s.viewmatrix, s.projmatrix, s.campos)
                                                for k in _tkey(t))
     hit = _VIEW_BLOCKS.get(key)
+    cur = torch.cuda.current_stream(device)
     if hit is None:
         view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
         proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
         cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
-        # other host threads may use the blocks on other streams right away: finish the copies once, here
-        torch.cuda.current_stream(device).synchronize()
+        # other host threads may pick the blocks up on other streams: they wait (on the device) for this event, nobody waits
+        # on the host
+        ev = torch.cuda.Event()
+        ev.record(cur)
         if len(_VIEW_BLOCKS) >= _VIEW_BLOCKS_MAX:
             _VIEW_BLOCKS.pop(next(iter(_VIEW_BLOCKS)))
-        hit = (view, proj, cam, [(s.viewmatrix, s.projmatrix, s.campos) for s in settings_list])
+        hit = (view, proj, cam, [(s.viewmatrix, s.projmatrix, s.campos) for s in settings_list], ev, cur.cuda_stream)
         _VIEW_BLOCKS[key] = hit
+    elif hit[5] != cur.cuda_stream:
+        cur.wait_event(hit[4])
     return hit[0], hit[1], hit[2]
 
 

@@ -296,9 +296,32 @@ void orc_inclusive_scan_u32(int64_t n, const uint32_t *in, uint32_t *out)
     for (int64_t i = 0; i < n; i++) { acc += in[i]; out[i] = acc; }
 }
 
-/* CR/rasterizer_impl.cu:70-111 */
-static void duplicate_with_keys(const orc_state *st)
+/* the same scan on `nthreads` threads: per-chunk sums, then per-chunk scans from the chunk's base (u32 wrap-around included) */
+static void inclusive_scan_u32_mt(int64_t n, const uint32_t *in, uint32_t *out, int nthreads)
 {
+    if (nthreads <= 1 || n < 65536) { orc_inclusive_scan_u32(n, in, out); return; }
+    uint32_t *part = (uint32_t *)calloc((size_t)nthreads + 1, sizeof(uint32_t));
+    const int64_t chunk = (n + nthreads - 1) / nthreads;
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int t = omp_get_thread_num();
+        const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
+        uint32_t acc = 0;
+        for (int64_t i = a; i < b; i++) acc += in[i];
+        part[t + 1] = acc;
+#pragma omp barrier
+#pragma omp single
+        for (int k = 0; k < nthreads; k++) part[k + 1] += part[k];
+        acc = part[t];
+        for (int64_t i = a; i < b; i++) { acc += in[i]; out[i] = acc; }
+    }
+    free(part);
+}
+
+/* CR/rasterizer_impl.cu:70-111: one (parallel) loop iteration per Gaussian, like the kernel's one thread per Gaussian */
+static void duplicate_with_keys(const orc_state *st, int nthreads)
+{
+#pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int idx = 0; idx < st->P; idx++) {
         if (st->radii[idx] > 0) {
             uint32_t off = (idx == 0) ? 0 : st->point_offsets[idx - 1];
@@ -348,9 +371,60 @@ void orc_sort_pairs(int64_t n, const uint64_t *kin, const uint32_t *vin, uint64_
     free(ka); free(kb); free(va); free(vb);
 }
 
+/* The same stable LSD sort on `nthreads` threads: every thread owns a contiguous chunk, counts its digits, and scatters its chunk
+ * in order to offsets[digit][thread] = (all smaller digits) + (the same digit in earlier chunks) -- stability is kept because
+ * chunks are taken in order and each chunk is walked in order. */
+static void sort_pairs_mt(int64_t n, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int end_bit, int nthreads)
+{
+    if (nthreads <= 1 || n < 65536) { orc_sort_pairs(n, kin, vin, kout, vout, end_bit); return; }
+    uint64_t *ka = (uint64_t *)malloc(sizeof(uint64_t) * n), *kb = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint32_t *va = (uint32_t *)malloc(sizeof(uint32_t) * n), *vb = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * 256 * (size_t)nthreads);
+    const int64_t chunk = (n + nthreads - 1) / nthreads;
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int t = omp_get_thread_num();
+        const int64_t a = t * chunk < n ? t * chunk : n, b = a + chunk < n ? a + chunk : n;
+        memcpy(ka + a, kin + a, sizeof(uint64_t) * (size_t)(b - a));
+        memcpy(va + a, vin + a, sizeof(uint32_t) * (size_t)(b - a));
+#pragma omp barrier
+        for (int shift = 0; shift < end_bit; shift += 8) {
+            const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+            const uint32_t mask = (1u << bits) - 1u;
+            const uint64_t *ks = ((shift / 8) & 1) ? kb : ka;
+            const uint32_t *vs = ((shift / 8) & 1) ? vb : va;
+            uint64_t *kd = ((shift / 8) & 1) ? ka : kb;
+            uint32_t *vd = ((shift / 8) & 1) ? va : vb;
+            int64_t *mine = cnt + 256 * (size_t)t;
+            memset(mine, 0, sizeof(int64_t) * 256);
+            for (int64_t i = a; i < b; i++) mine[(ks[i] >> shift) & mask]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                int64_t run = 0;
+                for (int d = 0; d < 256; d++)
+                    for (int k = 0; k < nthreads; k++) { const int64_t c = cnt[256 * (size_t)k + d]; cnt[256 * (size_t)k + d] = run; run += c; }
+            }
+            for (int64_t i = a; i < b; i++) {
+                const int64_t dst = mine[(ks[i] >> shift) & mask]++;
+                kd[dst] = ks[i];
+                vd[dst] = vs[i];
+            }
+#pragma omp barrier
+        }
+        const int passes = (end_bit + 7) / 8;
+        const uint64_t *kf = (passes & 1) ? kb : ka;
+        const uint32_t *vf = (passes & 1) ? vb : va;
+        memcpy(kout + a, kf + a, sizeof(uint64_t) * (size_t)(b - a));
+        memcpy(vout + a, vf + a, sizeof(uint32_t) * (size_t)(b - a));
+    }
+    free(ka); free(kb); free(va); free(vb); free(cnt);
+}
+
 /* CR/rasterizer_impl.cu:116-138; ranges must be zeroed first (cudaMemset, :310) */
 void orc_identify_tile_ranges(int64_t L, const uint64_t *keys, uint32_t *ranges)
 {
+#pragma omp parallel for schedule(static)
     for (int64_t idx = 0; idx < L; idx++) {
         uint32_t currtile = (uint32_t)(keys[idx] >> 32);
         if (idx == 0)
@@ -458,9 +532,10 @@ orc_state *orc_forward(const orc_inputs *in, int nthreads)
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int i = 0; i < in->P; i++) preprocess_one(in, st, focal_x, focal_y, i);
 
-    orc_inclusive_scan_u32(in->P, st->tiles_touched, st->point_offsets);
+    inclusive_scan_u32_mt(in->P, st->tiles_touched, st->point_offsets, nthreads);
     st->R = (int64_t)(int32_t)st->point_offsets[in->P - 1]; /* int num_rendered, :280-281 */
     int64_t vis = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : vis)
     for (int i = 0; i < in->P; i++) vis += st->radii[i] > 0;
     st->visible = vis;
 
@@ -469,12 +544,15 @@ orc_state *orc_forward(const orc_inputs *in, int nthreads)
     st->vals_unsorted = (uint32_t *)calloc(R + 1, 4);
     st->keys = (uint64_t *)calloc(R + 1, 8);
     st->vals = (uint32_t *)calloc(R + 1, 4);
-    duplicate_with_keys(st);
+    duplicate_with_keys(st, nthreads);
 
     int bit = (int)orc_get_higher_msb((uint32_t)(st->gridx * st->gridy));
-    orc_sort_pairs(st->R, st->keys_unsorted, st->vals_unsorted, st->keys, st->vals, 32 + bit);
+    sort_pairs_mt(st->R, st->keys_unsorted, st->vals_unsorted, st->keys, st->vals, 32 + bit, nthreads);
 
-    if (st->R > 0) orc_identify_tile_ranges(st->R, st->keys, st->ranges);
+    if (st->R > 0) {
+        omp_set_num_threads(nthreads);
+        orc_identify_tile_ranges(st->R, st->keys, st->ranges);
+    }
 
     const float *feature_ptr = in->colors_precomp ? in->colors_precomp : st->rgb;
     int64_t cf = 0, cb = 0;
@@ -501,7 +579,9 @@ void orc_mark_visible(int P, const float *means3D, const float *viewmatrix, cons
 /* ------------------------------------------------------------------ backward */
 
 /* CR/backward.cu:399-557 (renderCUDA bwd), one tile.  acc_* are double accumulators standing in for the
- * reference's float atomicAdd targets. */
+ * reference's float atomicAdd targets.  The 256 pixels of the tile first add into a buffer private to the calling thread,
+ * one row of nine doubles per list entry; the rows are then added to the shared accumulators, one atomic per (tile, entry,
+ * component) instead of one per (pixel, entry, component). */
 static void render_tile_backward(const orc_inputs *in, const orc_state *st, const float *colors, const float *dL_dpix,
                                  int tx, int ty, double *acc_mean2D, double *acc_conic, double *acc_opacity,
                                  double *acc_color)
@@ -511,6 +591,8 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
     const int toDo = (int)(r1 - r0);
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
+    if (toDo <= 0) return;
+    double *loc = (double *)calloc((size_t)toDo * 9, sizeof(double));   /* row = list position: x y | conic 0 1 3 | opacity | r g b */
     for (int ly = 0; ly < BLOCK_Y; ly++)
         for (int lx = 0; lx < BLOCK_X; lx++) {
             uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -528,6 +610,7 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
                 contributor--;
                 if (contributor >= (uint32_t)last_contributor) continue; /* unsigned compare as in :483 */
                 uint32_t id = st->vals[r1 - 1 - j];
+                double *row = loc + (size_t)(toDo - 1 - j) * 9;
                 float dx = st->means2D[2 * id] - pixf_x, dy = st->means2D[2 * id + 1] - pixf_y;
                 const float *co = st->conic_opacity + 4 * id;
                 float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -546,8 +629,7 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
                     float dL_dchannel = dL_dpixel[ch];
                     dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
                     float add = dchannel_dcolor * dL_dchannel;
-#pragma omp atomic
-                    acc_color[(size_t)id * 3 + ch] += (double)add;
+                    row[6 + ch] += (double)add;
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
@@ -562,20 +644,40 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
                 float a0 = dL_dG * dG_ddelx * ddelx_dx, a1 = dL_dG * dG_ddely * ddely_dy;
                 float c0 = -0.5f * gdx * dx * dL_dG, c1 = -0.5f * gdx * dy * dL_dG, c3 = -0.5f * gdy * dy * dL_dG;
                 float o0 = G * dL_dalpha;
-#pragma omp atomic
-                acc_mean2D[(size_t)id * 3 + 0] += (double)a0;
-#pragma omp atomic
-                acc_mean2D[(size_t)id * 3 + 1] += (double)a1;
-#pragma omp atomic
-                acc_conic[(size_t)id * 4 + 0] += (double)c0;
-#pragma omp atomic
-                acc_conic[(size_t)id * 4 + 1] += (double)c1;
-#pragma omp atomic
-                acc_conic[(size_t)id * 4 + 3] += (double)c3;
-#pragma omp atomic
-                acc_opacity[id] += (double)o0;
+                row[0] += (double)a0;
+                row[1] += (double)a1;
+                row[2] += (double)c0;
+                row[3] += (double)c1;
+                row[4] += (double)c3;
+                row[5] += (double)o0;
             }
         }
+    for (int k = 0; k < toDo; k++) {
+        const double *row = loc + (size_t)k * 9;
+        int any = 0;
+        for (int c = 0; c < 9; c++) any |= row[c] != 0.0;
+        if (!any) continue;
+        const uint32_t id = st->vals[r0 + k];
+#pragma omp atomic
+        acc_mean2D[(size_t)id * 3 + 0] += row[0];
+#pragma omp atomic
+        acc_mean2D[(size_t)id * 3 + 1] += row[1];
+#pragma omp atomic
+        acc_conic[(size_t)id * 4 + 0] += row[2];
+#pragma omp atomic
+        acc_conic[(size_t)id * 4 + 1] += row[3];
+#pragma omp atomic
+        acc_conic[(size_t)id * 4 + 3] += row[4];
+#pragma omp atomic
+        acc_opacity[id] += row[5];
+#pragma omp atomic
+        acc_color[(size_t)id * 3 + 0] += row[6];
+#pragma omp atomic
+        acc_color[(size_t)id * 3 + 1] += row[7];
+#pragma omp atomic
+        acc_color[(size_t)id * 3 + 2] += row[8];
+    }
+    free(loc);
 }
 
 /* CR/backward.cu:144-274 (computeCov2DCUDA) */
@@ -833,10 +935,13 @@ void orc_backward(const orc_inputs *in, const orc_state *st, const float *dL_dpi
     for (int t = 0; t < ntiles; t++)
         render_tile_backward(in, st, color_ptr, dL_dpix, t % st->gridx, t / st->gridx, acc_mean2D, acc_conic,
                              acc_opacity, acc_color);
-    for (size_t i = 0; i < (size_t)3 * P; i++) dL_dmean2D[i] += (float)acc_mean2D[i];
-    for (size_t i = 0; i < (size_t)4 * P; i++) dL_dconic[i] += (float)acc_conic[i];
-    for (size_t i = 0; i < (size_t)P; i++) dL_dopacity[i] += (float)acc_opacity[i];
-    for (size_t i = 0; i < (size_t)3 * P; i++) dL_dcolor[i] += (float)acc_color[i];
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)P; i++) {
+        for (int c = 0; c < 3; c++) dL_dmean2D[3 * i + c] += (float)acc_mean2D[3 * i + c];
+        for (int c = 0; c < 4; c++) dL_dconic[4 * i + c] += (float)acc_conic[4 * i + c];
+        dL_dopacity[i] += (float)acc_opacity[i];
+        for (int c = 0; c < 3; c++) dL_dcolor[3 * i + c] += (float)acc_color[3 * i + c];
+    }
     free(acc_mean2D); free(acc_conic); free(acc_opacity); free(acc_color);
 
     const float *cov3D_ptr = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;

@@ -9,7 +9,11 @@
                    validate/temp_state_dict.pt.  Third-party modules the reference imports but this path never
                    calls (MinkowskiEngine, open3d, cv2, ...) are replaced by MagicMock at import time.
 
-Usage: python tests/golden/make_golden_py.py
+  py_uvmap.npz   : /root/reference/plib/uv_mapping.py::UVMap (the texture lookup of the mesh sampler, through scipy's
+                   RegularGridInterpolator) on a seeded 7x5 RGB texture: uv inside, on the texel centres, on the borders, and
+                   outside [0,1) (wrap).  Pins pcrender.mesh_sample.uv_lookup.
+
+Usage: python tests/golden/make_golden_py.py [sh|camera|uvmap ...]
 """
 import os
 import sys
@@ -103,6 +107,29 @@ def camera_vectors():
     print("py_camera.npz written")
 
 
+def uvmap_vectors():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_uv_mapping", os.path.join(REF, "plib", "uv_mapping.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(77)
+    tex = rng.uniform(0, 1, (7, 5, 3)).astype(np.float32)
+    uv = np.concatenate([
+        rng.uniform(0, 1, (200, 2)),                                       # inside
+        rng.uniform(-2.5, 3.5, (100, 2)),                                  # outside: wrapped
+        (np.stack(np.meshgrid(np.arange(5), np.arange(7)), -1).reshape(-1, 2) + 0.5) / np.array([5.0, 7.0]),   # texel centres
+        np.array([[0.0, 0.0], [1.0, 1.0], [0.0, 0.999999], [0.999999, 0.0], [0.1, 0.0], [0.0, 0.07], [0.5, 1.0 - 1e-9]]),
+    ], 0)
+    out = mod.UVMap(tex)(uv)
+    np.savez_compressed(os.path.join(OUT, "py_uvmap.npz"), texture=tex, uv=uv, result=np.asarray(out, np.float64))
+    print("py_uvmap.npz written", out.shape)
+
+
 if __name__ == "__main__":
-    sh_vectors()
-    camera_vectors()
+    todo = sys.argv[1:] or ["sh", "camera", "uvmap"]
+    if "sh" in todo:
+        sh_vectors()
+    if "camera" in todo:
+        camera_vectors()
+    if "uvmap" in todo:
+        uvmap_vectors()

@@ -81,3 +81,75 @@ def test_obj_round_trip_and_point_cloud(tmp_path):
     assert pu["xyz_w"].shape == (1000, 3)
     with pytest.raises(NotImplementedError):
         ms.sample_point_cloud(m, 10, method="poisson_disk")
+
+
+# ------------------------------------------------------------------------------------------- textured meshes (OBJ + MTL + image)
+def _write_textured_quad(d, flip_second=False):
+    """A unit quad in the z = 0 plane (two triangles, CCW seen from +z) with vt spanning the whole texture, a 4x3 texture whose
+    texels are all different, plus a second quad with its own material / texture."""
+    from PIL import Image
+    tex = np.zeros((3, 4, 3), np.uint8)
+    for y in range(3):
+        for x in range(4):
+            tex[y, x] = (40 * x + 10, 60 * y + 20, 200 - 30 * x - 20 * y)
+    Image.fromarray(tex).save(str(d / "a.png"))
+    tex2 = np.full((2, 2, 3), 255, np.uint8)
+    tex2[0, 0] = (255, 0, 0)
+    Image.fromarray(tex2).save(str(d / "b.png"))
+    (d / "quad.mtl").write_text("newmtl matA\nKd 1 1 1\nmap_Kd a.png\n\nnewmtl plain\nKd 0.5 0.5 0.5\n\nnewmtl matB\nmap_Kd b.png\n")
+    (d / "quad.obj").write_text(
+        "mtllib quad.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
+        "v 2 0 0\nv 3 0 0\nv 3 1 0\nv 2 1 0\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "vn 0 0 1\n"
+        "usemtl matA\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+        "usemtl matB\nf 5/1/1 6/2/1 7/3/1 8/4/1\n")
+    return tex, tex2
+
+
+def test_uv_lookup_matches_the_reference_uvmap():
+    """golden vectors generated from /root/reference/plib/uv_mapping.py::UVMap (tests/golden/make_golden_py.py uvmap)"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "py_uvmap.npz"))
+    got = ms.uv_lookup(d["texture"], d["uv"])
+    np.testing.assert_allclose(got, d["result"], rtol=0, atol=1e-12)
+
+
+def test_textured_obj_colours_come_from_the_texture(tmp_path):
+    tex, tex2 = _write_textured_quad(tmp_path)
+    mesh = ms.read_obj(str(tmp_path / "quad.obj"))
+    assert mesh["triangle_uvs"].shape == (4, 3, 2) and len(mesh["textures"]) == 2
+    assert mesh["material_ids"].tolist() == [0, 0, 1, 1]          # matA -> texture 0, matB -> texture 1 ('plain' has no map_Kd)
+    # the image is stored flipped vertically, as open3d's OBJ reader does
+    np.testing.assert_array_equal(mesh["textures"][0], tex[::-1].astype(np.float32) / np.float32(255))
+    s = ms.sample_uniform(mesh["vertices"], mesh["faces"], 20000, seed=3, triangle_uvs=mesh["triangle_uvs"],
+                          material_ids=mesh["material_ids"], textures=mesh["textures"])
+    xyz, rgb = s["xyz"], s["rgb"]
+    left = xyz[:, 0] < 1.5
+    assert left.sum() > 5000 and (~left).sum() > 5000
+    # quad A: uv == (x, y) of the sample, so the colour is the bilinear texture value at (u, v) with v = 1 at the image's TOP row
+    # (OBJ convention); expected value from the unflipped image: row coordinate (1 - v) * h - 0.5
+    u, v = xyz[left, 0], xyz[left, 1]
+    h, w = tex.shape[:2]
+    t = tex.astype(np.float64) / 255.0
+    yy, xx = (1.0 - v) * h - 0.5, u * w - 0.5
+    y0, x0 = np.floor(yy).astype(int), np.floor(xx).astype(int)
+    fy, fx = (yy - y0)[:, None], (xx - x0)[:, None]
+    g = lambda a, b: t[np.mod(a, h), np.mod(b, w)]  # noqa: E731  (wrap padding)
+    want = (g(y0, x0) * (1 - fx) + g(y0, x0 + 1) * fx) * (1 - fy) + (g(y0 + 1, x0) * (1 - fx) + g(y0 + 1, x0 + 1) * fx) * fy
+    np.testing.assert_allclose(rgb[left], want, atol=1e-6)
+    # quad B uses the second texture only: red comes from its top-left texel, everything else is white
+    rb = rgb[~left]
+    assert rb.min() >= -1e-9 and rb.max() <= 1 + 1e-9 and np.allclose(rb[:, 0], 1.0, atol=1e-6)
+    ub, vb = xyz[~left, 0] - 2.0, xyz[~left, 1]
+    np.testing.assert_allclose(rb, ms.uv_lookup(mesh["textures"][1], np.stack([ub, vb], 1)), atol=1e-12)   # texture 1, not texture 0
+    centre = (np.abs(ub - 0.25) < 0.02) & (np.abs(vb - 0.75) < 0.02)    # around the centre of the top-left texel: (almost) pure red
+    assert centre.sum() > 5 and rb[centre][:, 1:].max() < 0.2
+    # normals: (0,0,1) interpolated, then turned against the ray direction (1,1,1) -> (0,0,-1)   (structures.py:3776-3780)
+    np.testing.assert_allclose(s["normal"], np.tile([0.0, 0.0, -1.0], (xyz.shape[0], 1)), atol=1e-12)
+    # the whole pipeline, quantised: attributes follow the first sample of every voxel
+    pc = ms.sample_point_cloud(mesh, 5000, method="uniform_quantized", seed=3)
+    assert pc["rgb"].shape == pc["xyz_w"].shape and pc["rgb"].dtype == np.float32
+    pc0 = ms.sample_point_cloud(dict(vertices=mesh["vertices"], faces=mesh["faces"]), 100, method="uniform", seed=1)
+    assert np.array_equal(pc0["rgb"], np.ones_like(pc0["xyz_w"]))        # no texture, no vertex colours: ones

@@ -5,7 +5,8 @@
               through the fused four-pass renderer; every pass against Oracle.forward (plain-C CPU oracle);
   8f-1        colour-only re-render (gsr_forward_recolor) against the oracle (not against the product);
   8f-2        a PLY written in open3d's layout, ingested with pcrender.ply, rendered by the HIP path, against the oracle;
-  8f-4        an OBJ mesh sampled with pcrender.mesh_sample (uniform and uniform_quantized), rendered, against the oracle;
+  8f-4        an OBJ mesh sampled with pcrender.mesh_sample (uniform and uniform_quantized; vertex colours, and a TEXTURED mesh:
+              vt + MTL map_Kd image), rendered, against the oracle;
   gradients   per-element / per-Gaussian-row bars (util.check_grads) and a directional finite difference of the HIP
               forward in position, scale and rotation.
 """
@@ -217,6 +218,46 @@ def test_mesh_sampled_cloud_vs_oracle(method, oracle, gpu_device, tmp_path):
     else:
         prim = ply.simple_render_primitives(pc["xyz_w"], pc["rgb"], sigma=0.004)
     _render_simple_vs_oracle(oracle, gpu_device, prim, 288, 272, 4, "mesh(%s)" % method)
+
+
+def _write_textured_box(d):
+    """The box again, as a real scan comes: OBJ with vt + vn, an MTL with a map_Kd image (a gradient with a checker on top)."""
+    from PIL import Image
+    yy, xx = np.mgrid[0:64, 0:96]
+    img = np.stack([xx * 255 // 95, yy * 255 // 63, 255 * (((xx // 8) + (yy // 8)) % 2)], -1).astype(np.uint8)
+    Image.fromarray(img).save(str(d / "skin.png"))
+    (d / "box.mtl").write_text("newmtl skin\nKd 1 1 1\nmap_Kd skin.png\n")
+    v = np.array([[x, y, z] for x in (-0.35, 0.35) for y in (-0.8, 0.8) for z in (-0.2, 0.2)], np.float64)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    with open(str(d / "box.obj"), "w") as f:
+        f.write("mtllib box.mtl\nusemtl skin\n")
+        for p_ in v:
+            f.write("v %.6f %.6f %.6f\n" % tuple(p_))
+        for k in range(6):                       # every face gets its own sixth of the texture
+            u0, u1 = k / 6.0, (k + 1) / 6.0
+            f.write("vt %.6f 0\nvt %.6f 0\nvt %.6f 1\nvt %.6f 1\n" % (u0, u1, u1, u0))
+        for k, (a, b, c, e) in enumerate(quads):
+            t = 4 * k
+            f.write("f %d/%d %d/%d %d/%d\nf %d/%d %d/%d %d/%d\n" % (a + 1, t + 1, b + 1, t + 2, c + 1, t + 3, a + 1, t + 1, c + 1, t + 3, e + 1, t + 4))
+    return img
+
+
+def test_textured_mesh_sampled_cloud_vs_oracle(oracle, gpu_device, tmp_path):
+    """8f-4 with the colours where the reference takes them from: the texture (OBJ vt + MTL map_Kd), read per sample through the
+    hit triangle's uv (structures.py:3746-3755).  Sampled, quantised, rendered by the HIP path, against the oracle."""
+    from pcrender import mesh_sample as ms, ply
+    img = _write_textured_box(tmp_path)
+    mesh = ms.read_obj(str(tmp_path / "box.obj"))
+    assert len(mesh["textures"]) == 1 and mesh["triangle_uvs"].shape == (12, 3, 2)
+    pc = ms.sample_point_cloud(mesh, 40000, method="uniform_quantized", seed=4)
+    rgb = pc["rgb"]
+    assert rgb.shape == pc["xyz_w"].shape and rgb.min() >= 0 and rgb.max() <= 1
+    # the colours really are the texture's: red follows u (six ramps), the blue channel is the checker (two values away from the edges)
+    assert len(np.unique(np.round(rgb[:, 0], 2))) > 50
+    assert ((rgb[:, 2] < 0.02) | (rgb[:, 2] > 0.98)).mean() > 0.7
+    means = ms.to_gaussian_means(pc["xyz_w"])
+    prim = ply.simple_render_primitives(means, rgb, sigma=2.0, scale_factor=448.0, voxelized=True)
+    _render_simple_vs_oracle(oracle, gpu_device, prim, 288, 272, 4, "textured mesh")
 
 
 # ------------------------------------------------------------------------------------------------ finite differences

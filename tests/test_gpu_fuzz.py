@@ -16,6 +16,15 @@ import os
 N_CASES = int(os.environ.get("GSR_FUZZ_CASES", "512"))
 
 
+# How often a case / a gradient row leaves through each fallback of the gradient comparison below.  The bars are principled
+# (float32 conditioning of the per-Gaussian chain), but nothing stops them from being widened until everything passes, so
+# the exits are counted and capped: test_fuzz_escape_hatches_stay_rare fails when more than 1 % of the cases or 1e-4 of the
+# rows compared need one.
+TALLY = dict(cases=0, rows=0, cases_exit_4x_reference=0, rows_exit_4x_reference=0, cases_exit_conditioning=0, rows_exit_conditioning=0)
+MAX_CASE_FRACTION = 0.01
+MAX_ROW_FRACTION = 1e-4
+
+
 def _ref():
     from oracle.oracle import Reference
     if not Reference.available("strict"):
@@ -70,12 +79,15 @@ def test_random_case_matches_reference_build(i, gpu_device):
     assert p["final_T"].tobytes() == r["final_T"].tobytes()
     assert p["out_color"].tobytes() == r["out_color"].tobytes()
     oracle_grads = None
+    TALLY["cases"] += 1
+    used_4x = used_cond = False
     for k, a in gp.items():
         b = gr[k]
         if a.size == 0 and b.size == 0:
             continue
         assert a.shape == b.shape, "case %d %s" % (i, k)
         assert np.isfinite(a).all(), "case %d %s" % (i, k)
+        TALLY["rows"] += int(a.shape[0])
         scale = np.abs(b).max()
         d_ref = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
         bad_el, bad_row, _ = util.grad_violations(a, b)
@@ -98,7 +110,12 @@ def test_random_case_matches_reference_build(i, gpu_device):
         a2, b2 = a.astype(np.float64).reshape(a.shape[0], -1), b.astype(np.float64).reshape(a.shape[0], -1)
         rn = np.linalg.norm(o, axis=1)
         r_lib, r_build = np.linalg.norm(a2 - o, axis=1), np.linalg.norm(b2 - o, axis=1)
+        plain = r_lib <= util.ROW_REL * rn + util.ROW_ABS * rn.max() + 1e-30          # the usual row bar, against the exact value
         ok = r_lib <= np.maximum(util.ROW_REL * rn + util.ROW_ABS * rn.max(), 4 * r_build) + 1e-30
+        n4 = int((ok & ~plain).sum())
+        if n4:
+            used_4x = True
+            TALLY["rows_exit_4x_reference"] += n4
         if not ok.all() and k in ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
             # Still outside: is the row simply that ill-conditioned?  (a) The render-level sums every float32 implementation
             # feeds into the chain carry ~1e-6 of relative rounding noise: push noise of that size through the float64 chain
@@ -123,5 +140,22 @@ def test_random_case_matches_reference_build(i, gpu_device):
                                          dtype=np.float32)[k].astype(np.float64)
             r_f32 = np.sqrt(((f32 - base).reshape(bad.size, -1) ** 2).sum(1))
             ok[bad] = r_lib[bad] <= np.maximum(6 * sigma, 4 * r_f32)
+            if ok[bad].any():
+                used_cond = True
+                TALLY["rows_exit_conditioning"] += int(ok[bad].sum())
         assert ok.all(), "case %d %s: %d rows; worst lib-exact %.3g (ref-exact %.3g there), lib-ref max %.3g, max|g| %.3g" % (
             i, k, int((~ok).sum()), r_lib[~ok].max(), r_build[~ok][np.argmax(r_lib[~ok])], d_ref, scale)
+    TALLY["cases_exit_4x_reference"] += int(used_4x)
+    TALLY["cases_exit_conditioning"] += int(used_cond)
+
+
+def test_fuzz_escape_hatches_stay_rare():
+    """Runs after the sweep (same process): how many cases / rows needed a fallback of the gradient comparison."""
+    if TALLY["cases"] == 0:
+        pytest.skip("no fuzz case ran in this process")
+    print("fuzz tally:", TALLY)
+    cases = TALLY["cases_exit_4x_reference"] + TALLY["cases_exit_conditioning"]
+    rows = TALLY["rows_exit_4x_reference"] + TALLY["rows_exit_conditioning"]
+    # (at least one case is always allowed: small sweeps must not fail on a single ill-conditioned splat)
+    assert cases <= max(1, int(MAX_CASE_FRACTION * TALLY["cases"])), TALLY
+    assert rows <= max(2, int(MAX_ROW_FRACTION * TALLY["rows"])), TALLY

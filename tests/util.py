@@ -239,9 +239,12 @@ def grad_violations(a, b):
     return bad_el, bad_row, float((d / bound).max())
 
 
-def check_grads(gp, go, tag, names=GRAD_NAMES):
-    """Assert every gradient tensor of the library (gp) against a reference (go): finite, same shape, per-element and
-    per-row bars of grad_violations."""
+WHOLE_TENSOR = 2e-4  # max|a - b| <= this x max|b| over the whole tensor (round 1's bar, kept next to the finer ones)
+
+
+def check_grads(gp, go, tag, names=GRAD_NAMES, whole_tensor=WHOLE_TENSOR):
+    """Assert every gradient tensor of the library (gp) against a reference (go): finite, same shape, the per-element and
+    per-row bars of grad_violations, and the whole-tensor bar max|a - b| <= whole_tensor * max|b| (None: skip it)."""
     for k in names:
         a, b = gp[k], go[k]
         if a.size == 0 and np.asarray(b).size == 0:
@@ -251,3 +254,7 @@ def check_grads(gp, go, tag, names=GRAD_NAMES):
         bad_el, bad_row, worst = grad_violations(a, b)
         assert bad_el == 0 and bad_row == 0, "%s %s: %d elements / %d rows outside the bar (worst element at %.2fx its bound)" % (
             tag, k, bad_el, bad_row, worst)
+        if whole_tensor is not None:
+            b64 = np.asarray(b, np.float64).reshape(a.shape)
+            dmax, scale = np.abs(np.asarray(a, np.float64) - b64).max(), np.abs(b64).max()
+            assert dmax <= whole_tensor * scale + 1e-30, "%s %s: max|a - b| = %.3g > %.1e * max|b| = %.3g" % (tag, k, dmax, whole_tensor, whole_tensor * scale)
