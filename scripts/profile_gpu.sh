@@ -20,11 +20,20 @@ if [ "$MODE" != "trace" ]; then
 # what FETCH_SIZE / WRITE_SIZE mean for this library's access patterns, on this box
 mkdir -p $OUT/calib
 if [ ! -x scripts/probe/fetch_calib ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/probe/fetch_calib scripts/probe/fetch_calib.hip; fi
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/calib/fetch -o c -- $PWD/scripts/probe/fetch_calib > $OUT/calib/calib.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/calib/write -o c -- $PWD/scripts/probe/fetch_calib > $OUT/calib/calib_w.log 2>&1)
+CAL=$PWD/scripts/probe/fetch_calib
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/calib/fetch -o c -- $CAL > $OUT/calib/calib.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/calib/write -o c -- $CAL > $OUT/calib/calib_w.log 2>&1)
 python $PWD/scripts/probe/fetch_calib_report.py $OUT/calib > $OUT/fetch_calibration.txt 2>&1
 cat $OUT/fetch_calibration.txt
 fi
+# host-side audit: GPU idle time, copies and blocking API calls per rasterizer call (single stream, no stage events)
+TL="python $PWD/bench.py --steps 144 --warmup 12 --repeats 1 --no-cpu-baseline --no-per-view --streams 1 --no-stage-events $EXTRA"
+(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --hip-trace --output-format csv -d $OUT/tl12 -o tl -- $TL > $OUT/tl12.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --hip-trace --output-format csv -d $OUT/tl1 -o tl -- $TL --views-per-call 1 > $OUT/tl1.log 2>&1)
+{ echo "== bench.py --streams 1 --no-stage-events, 12 views per rasterize_views call =="; python $PWD/scripts/timeline.py $OUT/tl12 0.4 12;
+  echo; echo "== the same through the per-view call (GaussianRasterizer.forward + backward per view) =="; python $PWD/scripts/timeline.py $OUT/tl1 0.4 1; } > $OUT/timeline.txt 2>&1
+cat $OUT/timeline.txt
+find $OUT/tl12 $OUT/tl1 -name "*.csv" -size +1M -delete
 python $PWD/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt
 # keep the merge small: drop the raw per-dispatch traces, keep stats + counter CSVs

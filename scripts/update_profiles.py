@@ -13,6 +13,8 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, "%s_bench_rocprofv3_summary.txt" % tag))
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, "%s_bench_kernel_stats.csv" % tag))
+if os.path.exists(os.path.join(src, "timeline.txt")):
+    shutil.copy(os.path.join(src, "timeline.txt"), os.path.join(dst, "%s_timeline.txt" % tag))
 if os.path.exists(os.path.join(src, "fetch_calibration.txt")):
     shutil.copy(os.path.join(src, "fetch_calibration.txt"), os.path.join(dst, "%s_fetch_calibration.txt" % tag))
 bench = json.loads([l for l in open(os.path.join(src, "bench.json")).read().splitlines() if l.startswith("{")][-1])
