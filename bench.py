@@ -335,12 +335,15 @@ def main():
                 for name, bv in (("literal_per_view_calls", False), ("views_in_one_call", True)):
                     for _ in range(2):
                         rgb_pass(bv)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
+                    its = []
                     for _ in range(5):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
                         rgb_pass(bv)
-                    torch.cuda.synchronize()
-                    rgb_time["ms_per_12_views"][name] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+                        torch.cuda.synchronize()
+                        its.append((time.perf_counter() - t1) * 1e3)
+                    rgb_time["ms_per_12_views"][name] = round(float(np.median(its)), 3)
+                    rgb_time.setdefault("iterations_ms", {})[name] = [round(x, 2) for x in its]
         except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
             rgb_time = {"error": repr(ex)}
     if use_dist:
@@ -446,6 +449,17 @@ def main():
                     orc.forward(sc, nthreads=nt)
                 return time.perf_counter() - t1
 
+            # os.cpu_count() is the machine, not what this container may use (a CPU quota makes 256 threads slower than 32):
+            # one probe frame at cores, cores/2, cores/4, cores/8 threads picks the thread count, which is what `cores` reports
+            host_cpus = cores
+            try:
+                host_cpus = min(cores, len(os.sched_getaffinity(0)))
+            except (AttributeError, OSError):
+                pass
+            probes = {}
+            for nt in sorted({max(1, host_cpus >> k) for k in range(4)}, reverse=True):
+                probes[nt] = cpu_frame(nt)
+            cores = min(probes, key=probes.get)
             cpu_frame(cores)                                              # warm-up (page faults, thread pool)
             times = sorted(cpu_frame(cores) for _ in range(max(1, args.cpu_frames)))
             cdt = float(np.median(times))
@@ -453,7 +467,9 @@ def main():
             cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                    "sample": "circle view 0 of the same workload, %s, plain-C oracle with OpenMP (parallel per-Gaussian stages, "
                              "parallel stable radix sort, per-thread gradient buffers): 1 warm-up + median of %d frames "
-                             "(min %.3f s, max %.3f s)" % (what, len(times), times[0], times[-1])}
+                             "(min %.3f s, max %.3f s); thread count chosen by one probe frame each at %s threads (os.cpu_count() = %d)"
+                             % (what, len(times), times[0], times[-1], "/".join("%d: %.2f s" % (k, v) for k, v in probes.items()),
+                                os.cpu_count() or 1)}
             if not args.no_cpu_1core:
                 c1 = cpu_frame(1)
                 cpu["one_core"] = {"value": round(1.0 / c1, 5), "unit": "frames/s", "cores": 1,

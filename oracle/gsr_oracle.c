@@ -584,7 +584,7 @@ void orc_mark_visible(int P, const float *means3D, const float *viewmatrix, cons
  * component) instead of one per (pixel, entry, component). */
 static void render_tile_backward(const orc_inputs *in, const orc_state *st, const float *colors, const float *dL_dpix,
                                  int tx, int ty, double *acc_mean2D, double *acc_conic, double *acc_opacity,
-                                 double *acc_color)
+                                 double *acc_color, double *loc /* the calling thread's rows: >= 9 x (longest list) doubles */)
 {
     const int W = in->W, H = in->H;
     const uint32_t r0 = st->ranges[2 * (ty * st->gridx + tx)], r1 = st->ranges[2 * (ty * st->gridx + tx) + 1];
@@ -592,7 +592,7 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
     if (toDo <= 0) return;
-    double *loc = (double *)calloc((size_t)toDo * 9, sizeof(double));   /* row = list position: x y | conic 0 1 3 | opacity | r g b */
+    memset(loc, 0, (size_t)toDo * 9 * sizeof(double));                  /* row = list position: x y | conic 0 1 3 | opacity | r g b */
     for (int ly = 0; ly < BLOCK_Y; ly++)
         for (int lx = 0; lx < BLOCK_X; lx++) {
             uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -677,7 +677,6 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
 #pragma omp atomic
         acc_color[(size_t)id * 3 + 2] += row[8];
     }
-    free(loc);
 }
 
 /* CR/backward.cu:144-274 (computeCov2DCUDA) */
@@ -931,10 +930,22 @@ void orc_backward(const orc_inputs *in, const orc_state *st, const float *dL_dpi
     double *acc_mean2D = (double *)calloc((size_t)3 * P, 8), *acc_conic = (double *)calloc((size_t)4 * P, 8);
     double *acc_opacity = (double *)calloc((size_t)P, 8), *acc_color = (double *)calloc((size_t)3 * P, 8);
     const int ntiles = st->gridx * st->gridy;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
-    for (int t = 0; t < ntiles; t++)
-        render_tile_backward(in, st, color_ptr, dL_dpix, t % st->gridx, t / st->gridx, acc_mean2D, acc_conic,
-                             acc_opacity, acc_color);
+    size_t longest = 1;
+    for (int t = 0; t < ntiles; t++) {
+        const size_t len = (size_t)(st->ranges[2 * t + 1] - st->ranges[2 * t]);
+        if (len > longest) longest = len;
+    }
+    /* one buffer of per-entry rows per thread, allocated once (a calloc per tile from 256 threads is all page faults) */
+    double *rows = (double *)malloc(sizeof(double) * 9 * longest * (size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
+    {
+        double *loc = rows + (size_t)omp_get_thread_num() * 9 * longest;
+#pragma omp for schedule(dynamic, 4)
+        for (int t = 0; t < ntiles; t++)
+            render_tile_backward(in, st, color_ptr, dL_dpix, t % st->gridx, t / st->gridx, acc_mean2D, acc_conic,
+                                 acc_opacity, acc_color, loc);
+    }
+    free(rows);
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int64_t i = 0; i < (int64_t)P; i++) {
         for (int c = 0; c < 3; c++) dL_dmean2D[3 * i + c] += (float)acc_mean2D[3 * i + c];

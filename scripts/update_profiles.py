@@ -86,6 +86,25 @@ for f in glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"),
             sq[k][r["Counter_Name"]] += float(r["Counter_Value"]); sql[k].add(r["Dispatch_Id"])
 out["valu_wave_instructions_per_launch"] = {k: int(v["SQ_INSTS_VALU"] / max(len(sql[k]), 1)) for k, v in sq.items() if "SQ_INSTS_VALU" in v}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# the lease's own bench line could not know these counters yet (they were collected after it, minutes later on the same box):
+# complete its roofline block from them, and say so
+rf = bench.get("roofline")
+if rf:
+    kn = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>"}.get(rf["kernel"], rf["kernel"])
+    rf["traffic"] = out["bytes_per_launch"].get(kn)
+    rf["traffic_source"] = ("filled in by scripts/update_profiles.py from the PMC passes of the SAME lease (profiles/pmc_traffic.json): "
+                            "(%s x FETCH_SIZE + WRITE_SIZE) per launch" % factor.get(kn, factor["default"]))
+    if kn in avg_us:
+        rf["profile_avg_ms"] = round(avg_us[kn] / 1e3, 4)
+        rf["frac_profile"] = round(rf["algorithmic_bytes"] / (avg_us[kn] * 1e-6) / 1e9 / rf["peak"], 5)
+        rel = rf["avg_ms"] / (avg_us[kn] / 1e3)
+        rf["live_vs_profile"] = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
+    vi = out["valu_wave_instructions_per_launch"].get(kn)
+    if vi:
+        rate = vi / (rf["avg_ms"] * 1e-3)
+        rf["valu"] = {"wave_instructions": int(vi), "G_wave_instr_per_s": round(rate / 1e9, 1), "peak_G_wave_instr_per_s": 1228.9,
+                      "frac": round(rate / 1e9 / 1228.9, 4), "source": "SQ_INSTS_VALU per launch (same lease); duration measured live"}
+    json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("key", "fetch_factor", "avg_us")}, indent=1, sort_keys=True))
 print(json.dumps(out["bytes_per_launch"], indent=1, sort_keys=True))
 print(out["valu_wave_instructions_per_launch"])
