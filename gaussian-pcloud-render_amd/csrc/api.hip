@@ -527,10 +527,12 @@ int gsr_selftest(gsr_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
     float* d = nullptr;
-    if (hipMalloc(&d, 128 * sizeof(float)) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
+    if (hipMalloc(&d, 256 * sizeof(float)) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
     const int rr = selftest_reduce(s, d);
+    const int rm = rr == 0 ? selftest_mm(s, d) : 0;
     (void)hipFree(d);
     if (rr != 0) return fail(GSR_ERR_HIP, "[gsr] selftest: wave reduction wrong at check %d", rr);
+    if (rm != 0) return fail(GSR_ERR_HIP, "[gsr] selftest: matrix-core pixel contraction wrong at check %d", rm);
 
     const int64_t n = 100003;
     std::vector<uint32_t> hk(n), hv(n), order(n);

@@ -196,6 +196,99 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
     return 0;
 }
 
+// ---- wave reduction on the matrix cores ------------------------------------------------------------------
+// The nine sums of an entry over the 64 pixels of a quadrant are a contraction over the pixel index:
+//   dL/d{mean2D, conic, opacity} are moments  sum_p q[e][p] * {1, cx, cy, cx^2, cx cy, cy^2}(p)  of ONE per-(entry, pixel)
+//   weight q = G * dL_dalpha (cx, cy = pixel offsets from the quadrant centre: per-LANE constants), shifted to the
+//   splat's own centre afterwards (dx = bx - cx with bx = mean.x - quadrant centre, a per-ENTRY constant);
+//   dL/dcolour[ch] = sum_p u[e][p] * dL_dpixel[ch][p] with u = alpha * T.
+// So a batch of 8 entries is a 16-row matrix (rows 0..7 q, rows 8..15 u) x 64 pixels, written to LDS by the lanes
+// that own the pixels and multiplied by a constant 64 x 16 basis with sixteen v_mfma_f32_16x16x4_f32 (exact fp32, on the
+// otherwise idle matrix pipe): D[i][j] = sum_p F[i][p] * data[j][p].  Basis rows i = 4 g + r are laid out so that the four
+// accumulator registers of a lane (g = lane >> 4, column j = lane & 15) hold everything ONE output needs:
+//   g = 0: 1, cx, cy, cx^2 -> conic.x, mean.x     g = 1: 1, cx, cy, cx cy -> conic.y, mean.y
+//   g = 2: 1, cx, cy, cy^2 -> conic.w, opacity    g = 3: dL_dpixel r, g, b -> colour (u columns only)
+// No cross-lane instruction is left.  K step s = 4 m + r covers pixel 16 m + 4 k + r (k = lane >> 4), so a lane's four
+// ds_read_b128 of its row are the B operands of the sixteen steps.
+constexpr int MM_STRIDE = 68;   // floats per LDS row: 272 B, consecutive rows 4 banks apart (conflict-free b128 reads)
+
+__device__ __forceinline__ void mm_basis(float (&am)[16], uint32_t lane)
+{
+    const uint32_t i = lane & 15u, k = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const uint32_t p = 16u * (uint32_t)(s >> 2) + 4u * k + (uint32_t)(s & 3);
+        const float cx = (float)(p & 7u) - 3.5f, cy = (float)(p >> 3) - 3.5f;
+        const uint32_t c = i & 3u;
+        const float f = c == 0 ? 1.f : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
+        am[s] = i < 12u ? f : 0.f;
+    }
+}
+// rows 12..14 of the basis: this item's dL_dpixel, staged as rows 0..2 of the LDS matrix
+__device__ __forceinline__ void mm_basis_dpx(float (&am)[16], const float* mrow, uint32_t lane)
+{
+    const uint32_t i = lane & 15u, k = lane >> 4;
+    if (i >= 12u && i < 15u) {
+        const f32x4* src = (const f32x4*)(mrow + (i - 12u) * MM_STRIDE + 4u * k);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const f32x4 t = src[4 * m];
+            am[4 * m + 0] = t.x; am[4 * m + 1] = t.y; am[4 * m + 2] = t.z; am[4 * m + 3] = t.w;
+        }
+    }
+}
+__device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am)[16], uint32_t lane)
+{
+    const f32x4* rp = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const f32x4 b = rp[4 * m];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 0], b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 1], b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 2], b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 3], b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ void k_selftest_mm(float* out256)
+{
+    __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];
+    const uint32_t lane = threadIdx.x;
+    float am[16];
+    mm_basis(am, lane);
+    // "dL_dpixel" of pixel p, channel c: ((p + 2 c) % 5) - 2
+    for (int c = 0; c < 3; c++) mrow[c * MM_STRIDE + lane] = (float)((int)((lane + 2u * c) % 5u) - 2);
+    mm_basis_dpx(am, mrow, lane);
+    // data[j][p] = ((7 j + 3 p) % 11) - 5: small integers, every sum exact
+    for (int j = 0; j < 16; j++) mrow[j * MM_STRIDE + lane] = (float)((int)((7u * j + 3u * lane) % 11u) - 5);
+    const f32x4 acc = mm_contract(mrow, am, lane);
+    out256[lane * 4 + 0] = acc.x; out256[lane * 4 + 1] = acc.y; out256[lane * 4 + 2] = acc.z; out256[lane * 4 + 3] = acc.w;
+}
+
+int selftest_mm(hipStream_t stream, float* d_scratch256)
+{
+    hipLaunchKernelGGL(k_selftest_mm, dim3(1), dim3(64), 0, stream, d_scratch256);
+    float h[256];
+    if (hipMemcpyAsync(h, d_scratch256, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    for (int l = 0; l < 64; l++)
+        for (int r = 0; r < 4; r++) {
+            const int i = 4 * (l >> 4) + r, j = l & 15;
+            double want = 0;
+            for (int p = 0; p < 64; p++) {
+                const double cx = (p & 7) - 3.5, cy = (p >> 3) - 3.5;
+                const int c = i & 3;
+                double f = c == 0 ? 1. : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
+                if (i >= 12) f = i < 15 ? (double)((p + 2 * (i - 12)) % 5 - 2) : 0.;
+                want += f * (double)((7 * j + 3 * p) % 11 - 5);
+            }
+            if ((double)h[l * 4 + r] != want) return 1 + l * 4 + r;
+        }
+    return 0;
+}
+
 #if defined(GSR_STATS) && defined(GSR_STATS_HITS)
 // instrumentation build only (GSR_EXTRA_FLAGS="-DGSR_STATS -DGSR_STATS_HITS"; the atomics slow the kernel 100x, so they are
 // kept out of the timing build): 0 rounds, 1 staged entries, 2 groups, 3 groups with a hit,
@@ -274,7 +367,27 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     a.grad_rec = at_view(a.grad_rec, a.gr_stride, view);
     a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
+#ifdef GSR_BWD_BUTTERFLY
     __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
+#else
+    // group 16 keeps the entries of a batch that is still open when its round ends (the next round restages groups 0..15)
+    __shared__ __attribute__((aligned(16))) float stage[17 * QUAD_WORDS];
+    __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];   // 8 entries x {q, u} rows x 64 pixels
+    float am[16];                                                          // A operands of the 16 K steps (basis)
+    mm_basis(am, threadIdx.x);
+    // what this lane does with its four accumulator values after a batch's contraction (see mm_basis): g < 3 on q columns,
+    // g = 3 on u columns
+    const uint32_t mm_g = threadIdx.x >> 4, mm_j = threadIdx.x & 15u;
+    const bool mm_u = mm_g == 3u && mm_j >= 8u;
+    const uint32_t mm_gb = (mm_j >> 2) & 1u, mm_k4 = mm_j & 3u;     // own column: group of the batch, slot in the group
+    // after the hand-over (flush below): which component of grad_rec this lane adds to for entries 0..3 (A) and 4..7 (B)
+    const uint32_t mm_c2 = mm_g == 2u ? 8u : mm_g;
+    const bool mm_onA = mm_g < 3u ? mm_j < 8u : (mm_j < 4u || mm_j >= 8u), mm_onB = mm_g < 3u ? mm_j < 8u : mm_j >= 4u;
+    const uint32_t mm_cA = mm_g < 3u ? (mm_j < 4u ? 2u + mm_g : mm_c2) : (mm_j >= 12u ? 6u : mm_j >= 8u ? 5u : 7u);
+    const uint32_t mm_cB = mm_g < 3u ? (mm_j < 4u ? mm_c2 : 2u + mm_g) : (mm_j >= 12u ? 5u : mm_j >= 8u ? 6u : 7u);
+    const uint32_t mm_offP = mm_g == 0 ? 8u : 12u, mm_offQ = mm_g == 0 ? 12u : 16u;   // conic A|B resp. B|C
+    const float mm_dd = -(mm_g == 0 ? (float)(0.5 * a.W) : (float)(0.5 * a.H));
+#endif
 #ifdef GSR_STATS
     BW_T(tw0);
     unsigned long long tw_wait = 0, tw_setup = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_groups = 0, n_items_done = 0;
@@ -306,7 +419,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t o = __shfl_xor(m, d, 64);
             m = m > o ? m : o;
         }
-        total = (int)m;
+        total = (int)__builtin_amdgcn_readfirstlane(m);   // every lane holds the maximum: tell the compiler it is uniform
     }
     // this item's slice of the list: entries [lo, hi0), walked last first
     const int lo = (int)(chunk << BWD_CHUNK_SHIFT);
@@ -326,13 +439,20 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     bg_dot_dpixel += a.bg[0] * dpx0;
     bg_dot_dpixel += a.bg[1] * dpx1;
     bg_dot_dpixel += a.bg[2] * dpx2;
+#ifdef GSR_BWD_BUTTERFLY
     const float ddelx_dx = (float)(0.5 * a.W);
     const float ddely_dy = (float)(0.5 * a.H);
+#else
+    mrow[lane] = dpx0; mrow[MM_STRIDE + lane] = dpx1; mrow[2 * MM_STRIDE + lane] = dpx2;
+    mm_basis_dpx(am, mrow, lane);
+    const float mm_sx = x0f + 3.5f, mm_sy = y0f + 3.5f;   // quadrant centre
+#endif
 
     // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3 of the group,
     // component c = i & 7 in {mean2D.x, mean2D.y, conic.x, conic.y, conic.w, colour r, g, b}; odd lanes 1, 17, 33, 49
     // own the opacity gradient (component 8) of entries 0..3.  target = grad_rec[id][c]: the nine atomics of an entry
     // fall into one 64-B line.
+#ifdef GSR_BWD_BUTTERFLY
     int tgt_k = (int)(lane >> 4), tgt_c = 0;
     bool tgt_on = false;
     if ((lane & 1u) == 0) {
@@ -342,6 +462,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         tgt_c = 8;
         tgt_on = true;
     }
+#endif
 
     // the staging area starts as zeros, so slots of a partly filled last group always hold finite values (their
     // opacity is set to 0 every round, which is what keeps them from ever hitting)
@@ -383,6 +504,9 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     }
 #ifdef GSR_STATS
     { BW_T(ti1); tw_setup += ti1 - ti0; }
+#endif
+#ifndef GSR_BWD_BUTTERFLY
+    uint32_t nb = 0, gq0 = 0, gq1 = 0;   // groups in the open batch (it may span rounds), their staging groups
 #endif
     for (int hi = hi0; hi > lo; hi -= 64) {
 #ifdef GSR_STATS
@@ -428,7 +552,12 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         BW_T(tr1);
         tw_stage += tr1 - tr0;
 #endif
-        while (mask != 0) {
+#ifndef GSR_BWD_BUTTERFLY
+        const bool last_round = hi - 64 <= lo;
+#endif
+        for (;;) {
+          const bool more = mask != 0;
+          if (more) {
             BWD_STAT(2, 1);
 #ifdef GSR_STATS
             n_groups++;
@@ -473,7 +602,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 hits[k + 1] = (ef[k + 1] < last_contributor) && !(power.y > 0.0f) && !(alphas[k + 1] < 1.0f / 255.0f);
                 any_lane_hit = any_lane_hit || hits[k] || hits[k + 1];
             }
-            if (!__any(any_lane_hit)) continue;
+            if (__any(any_lane_hit)) {
 #if defined(GSR_STATS) && defined(GSR_STATS_HITS)
             BWD_STAT(3, 1);
             for (int k = 0; k < BGRP; k++) {
@@ -514,6 +643,22 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 last_d = d;
                 last_alpha = alpha;
             }
+#ifndef GSR_BWD_BUTTERFLY
+            // Phase 2 is two weights per (pixel, entry): q = G dL_dalpha and u = alpha T, one LDS row each; the sums over the
+            // pixels are taken by the matrix cores once two groups have been written (mm_basis)
+            {
+                float* rq = mrow + nb * 4u * MM_STRIDE + lane;
+#pragma unroll
+                for (int k = 0; k < BGRP; k += 2) {
+                    const f32x2 dLa2 = {dLa[k], dLa[k + 1]}, Gh2 = {Gh[k], Gh[k + 1]};
+                    const f32x2 op = Gh2 * dLa2;
+                    rq[k * MM_STRIDE] = op.x; rq[(k + 1) * MM_STRIDE] = op.y;
+                    rq[(8 + k) * MM_STRIDE] = dch[k]; rq[(9 + k) * MM_STRIDE] = dch[k + 1];
+                }
+                if (nb == 0) gq0 = (uint32_t)(quad - 1); else gq1 = (uint32_t)(quad - 1);
+                nb++;
+            }
+#else
             // Phase 2: the 4 x 9 partial derivatives of this lane's pixel, again on entry pairs
             float v[32], xo[BGRP];
 #pragma unroll
@@ -547,7 +692,65 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             // this lane's entry id, straight from the id row of the group
             const uint32_t id = __builtin_bit_cast(uint32_t, stage[(quad - 1) * QUAD_WORDS + 36 + tgt_k]);
             if (tgt_on && val != 0.f) atomicAdd(a.grad_rec + (size_t)id * GRAD_REC_WORDS + tgt_c, val);
+#endif
+            }   // any lane hit
+          }     // more
+#ifndef GSR_BWD_BUTTERFLY
+#ifdef GSR_X_NOFLUSH
+          if (nb == 2u) nb = 0;
+#else
+          if (nb == 2u || (!more && nb != 0u && last_round)) {
+            // per-entry constants and targets first: their LDS round trips pass while the matrix pipe works
+            const float* e = stage + (mm_gb ? gq1 : gq0) * QUAD_WORDS + mm_k4;
+            const float eX = e[0], eY = e[4], cP = e[mm_offP], cQ = e[mm_offQ], cO = e[20];
+            const uint32_t idA = __builtin_bit_cast(uint32_t, stage[gq0 * QUAD_WORDS + 36u + mm_k4]);
+            const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
+            // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
+#ifdef GSR_X_NOMFMA
+            const f32x4* rp_ = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
+            const f32x4 acc = rp_[0] + rp_[4] + rp_[8] + rp_[12];
+#else
+            const f32x4 acc = mm_contract(mrow, am, lane);
+#endif
+            const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
+            const float S1 = acc.x, Sx = acc.y, Sy = acc.z, V3 = acc.w;
+            const float Dx = __builtin_fmaf(bx, S1, -Sx), Dy = __builtin_fmaf(by, S1, -Sy);   // sum q dx, sum q dy
+            // second moments about the splat centre: sum q dx^2 = bx Dx - bx Sx + Sxx, sum q dx dy = by Dx - bx Sy + Sxy,
+            // sum q dy^2 = by Dy - by Sy + Syy
+            const float t2 = __builtin_fmaf(mm_g == 0 ? bx : by, mm_g == 2u ? Dy : Dx,
+                                            __builtin_fmaf(-(mm_g == 2u ? by : bx), mm_g == 0 ? Sx : Sy, V3));
+            float o1 = -0.5f * cO * t2;                                                  // conic x | y | w
+            float o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                   // mean2D x | y
+            if (mm_g == 2u) o2 = S1;                                                     // opacity
+            if (mm_u) { o1 = acc.x; o2 = acc.y; }                                        // colour r, g (row 3, u columns)
+            const float o3 = acc.z;                                                      // colour b
+            // Hand the second and third values to idle lanes of the same 16-lane row, so that the nine values of an entry
+            // sit in nine lanes and ONE atomic instruction serves four entries (the nine addresses of an entry fall into
+            // one 64-B record: atomics are priced per line touched).  vA: entries 0..3 of the batch, vB: entries 4..7.
+            float vA = dpp_mov<0x114, 0xf, 0xa>(o1, o2);   // row_shr:4 -> banks 1, 3: o2 of the lane four below
+            vA = dpp_mov<0x128, 0x8, 0x1>(vA, o3);         // row_ror:8, row 3 bank 0: colour b of lane + 8
+            float vB = dpp_mov<0x104, 0xf, 0x5>(o1, o2);   // row_shl:4 -> banks 0, 2: o2 of the lane four above
+            vB = dpp_mov<0x128, 0x8, 0x2>(vB, o3);         // row 3 bank 1: colour b of lane + 8
+#ifndef GSR_X_NOATOM
+            if (mm_onA && vA != 0.f) atomicAdd(a.grad_rec + (size_t)idA * GRAD_REC_WORDS + mm_cA, vA);
+            if (mm_onB && nb == 2u && vB != 0.f) atomicAdd(a.grad_rec + (size_t)idB * GRAD_REC_WORDS + mm_cB, vB);
+#else
+            if (vA + vB + __builtin_bit_cast(float, idA + idB) == 123.456f) a.grad_rec[0] = 1.f;
+#endif
+            nb = 0;
+          }
+#endif
+#endif
+          if (!more) break;
         }
+#ifndef GSR_BWD_BUTTERFLY
+        // a half-filled batch waits for the next round's first group: keep its entries' constants out of the restaging's way
+        if (nb == 1u && gq0 != 16u) {
+            if (lane < (uint32_t)QUAD_WORDS) stage[16 * QUAD_WORDS + lane] = stage[gq0 * QUAD_WORDS + lane];
+            gq0 = 16u;
+        }
+#endif
 #ifdef GSR_STATS
         BW_T(tr2);
         tw_eval += tr2 - tr1;
