@@ -521,17 +521,15 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     return GSR_OK;
 }
 
-// Device self-test of internal primitives that have no observable output of their own: the transposed wave
-// reduction of the backward pass, and the stable radix sort against std::stable_sort on random keys with many ties.
+// Device self-test of internal primitives that have no observable output of their own: the matrix-core pixel
+// contraction of the render backward, and the stable radix sort against std::stable_sort on random keys with many ties.
 int gsr_selftest(gsr_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
     float* d = nullptr;
     if (hipMalloc(&d, 256 * sizeof(float)) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
-    const int rr = selftest_reduce(s, d);
-    const int rm = rr == 0 ? selftest_mm(s, d) : 0;
+    const int rm = selftest_mm(s, d);
     (void)hipFree(d);
-    if (rr != 0) return fail(GSR_ERR_HIP, "[gsr] selftest: wave reduction wrong at check %d", rr);
     if (rm != 0) return fail(GSR_ERR_HIP, "[gsr] selftest: matrix-core pixel contraction wrong at check %d", rm);
 
     const int64_t n = 100003;

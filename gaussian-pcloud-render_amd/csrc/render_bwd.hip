@@ -13,15 +13,16 @@
 // back-to-front recurrences need to start in the middle, so the slices of a long list are walked concurrently and the
 // longest serial walk in this kernel is BWD_CHUNK entries.
 //
-// Where the reference issues 9 float atomicAdds per contributing PAIR (up to 256 pixels hammering one Gaussian),
-// the 4 x 9 partial sums of a group are reduced over the 64 lanes FIRST, by a transposed butterfly: at every
-// level a lane keeps half of its values and hands the other half to its partner, so 32 values cost 72 instructions
-// instead of 32 x 6 (v_permlane32_swap / v_permlane16_swap for lane bits 5 and 4, DPP row_ror:8, row_shl/shr:4 and
-// quad_perm for bits 3..0).  Afterwards lane 2i holds the wave total of value i, and ONE global float atomic
-// instruction per group (36 active lanes, zero sums skipped) updates the per-Gaussian gradients: at most 9 atomics
-// per (quadrant, entry) instead of 9 x 64.
-// Summation order differs from the reference's (undefined) atomic order and 1/(1-alpha) is v_rcp_f32 (1 ulp);
-// results agree to fp32 rounding (tests: <= 2e-4 of max|g| per tensor, observed ~1e-6).
+// Where the reference issues 9 float atomicAdds per contributing PAIR (up to 256 pixels hammering one Gaussian), the
+// sums over the 64 pixels of the quadrant are taken FIRST, and not by cross-lane instructions: every one of the nine
+// gradients is a pixel-weighted sum of one of two per-(pixel, entry) weights, i.e. a small dense contraction over the
+// pixel index, which is what the matrix cores do ("wave reduction on the matrix cores" below: two LDS rows per entry,
+// sixteen v_mfma_f32_16x16x4_f32 per batch of eight entries, exact fp32).  Two global float atomic instructions per
+// batch (36 lanes each, the nine addresses of an entry inside one 64-B record, zero sums skipped) then update the
+// per-Gaussian gradient records: 9 atomics per (quadrant, entry) instead of 9 x 64.
+// Summation order differs from the reference's (undefined) atomic order, the second moments are shifted from the
+// quadrant centre to the splat centre after the sum, and 1/(1-alpha) is v_rcp_f32 (1 ulp); results agree to fp32
+// rounding (tests: <= 2e-4 of max|g| per tensor, observed ~1e-6).
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -85,117 +86,6 @@ __device__ __forceinline__ float dpp_mov(float old, float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
                                                                  ROW_MASK, BANK_MASK, false));
 }
-__device__ __forceinline__ float xor1(float v) { return dpp_mov<0xB1, 0xf, 0xf>(0.f, v); }   // quad_perm [1,0,3,2]
-__device__ __forceinline__ float xor2(float v) { return dpp_mov<0x4E, 0xf, 0xf>(0.f, v); }   // quad_perm [2,3,0,1]
-__device__ __forceinline__ float xor8(float v) { return dpp_mov<0x128, 0xf, 0xf>(0.f, v); }  // row_ror:8
-__device__ __forceinline__ float xor4(float v)
-{
-    // banks 1,3 take lane-4 (row_shr:4), banks 0,2 take lane+4 (row_shl:4)
-    const float t = dpp_mov<0x114, 0xf, 0xa>(0.f, v);
-    return dpp_mov<0x104, 0xf, 0x5>(t, v);
-}
-// v_permlane32_swap a, b : lanes 32-63 of a <-> lanes 0-31 of b, i.e. a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32];
-// v_permlane16_swap a, b : odd rows of a <-> even rows of b,  a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3].
-// a' + b' then holds, in the lanes whose bit 5 (resp. 4) is 0, a summed over the lane pair, and in the other lanes b
-// summed over the pair: one halving level of the transposed reduction for two instructions per value pair.
-// Issued as inline asm, eight swaps per statement: (1) clang 22 / ROCm 7.2 lowers __builtin_amdgcn_permlane{16,32}_swap
-// so that both elements of its result are the FIRST output (the IR adds extractvalue 0 to itself), (2) hipcc pads no
-// wait states inside asm, so each block carries its own s_nop 1 in front (VALU write -> permlane swap read, 2 wait
-// states on gfx950) and behind (swap write -> VALU read).
-#define GSR_SWAP8(OP, A, B)                                                                                               \
-    asm volatile("s_nop 1\n\t" OP " %0, %8\n\t" OP " %1, %9\n\t" OP " %2, %10\n\t" OP " %3, %11\n\t" OP " %4, %12\n\t" OP \
-                 " %5, %13\n\t" OP " %6, %14\n\t" OP " %7, %15\n\ts_nop 1"                                                \
-                 : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(B[0]),   \
-                   "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]))
-#define GSR_SWAP2(OP, A0, A1, B0, B1)                                                                  \
-    asm volatile("s_nop 1\n\t" OP " %0, %2\n\t" OP " %1, %3\n\ts_nop 1" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1))
-
-// Transposed reduction of 32 per-lane values over the 64 lanes: on return lane l holds the wave-wide sum of
-// v[(l >> 1) & 31].  ~75 instructions instead of 32 x 6.
-__device__ __forceinline__ float reduce32_transposed(const float (&v)[32], uint32_t lane)
-{
-    float a[8], b[8], r[16], s[8], t[4], u[2];
-    // bit 5: pairs (v[i], v[i+16]) -> r[i] = value i + 16*b5
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { a[i] = v[8 * h + i]; b[i] = v[8 * h + i + 16]; }
-        GSR_SWAP8("v_permlane32_swap_b32", a, b);
-#pragma unroll
-        for (int i = 0; i < 8; i++) r[8 * h + i] = a[i] + b[i];
-    }
-    // bit 4: pairs (r[i], r[i+8]) -> s[i] = value i + 8*b4 + 16*b5
-#pragma unroll
-    for (int i = 0; i < 8; i++) { a[i] = r[i]; b[i] = r[i + 8]; }
-    GSR_SWAP8("v_permlane16_swap_b32", a, b);
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = a[i] + b[i];
-    const bool b1 = (lane & 2u) != 0;
-    // bit 3: lanes 0-7 of a row keep value i, lanes 8-15 keep value i+4; the partner (lane ^ 8 = row_ror:8) holds the other
-    // half of the same value.  The two cases are two DPP adds with complementary bank masks writing one register: no
-    // selects.  (s_nop: VALU write -> DPP read needs two wait states and hipcc pads nothing inside or around asm.)
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                 "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc"
-                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
-                 : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]));
-    // bit 2: banks 0,2 (lane & 4 == 0) keep value i and read lane+4 (row_shl:4), banks 1,3 keep value i+2 and read lane-4
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                 "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-                 "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-                 "s_nop 1"
-                 : "=&v"(u[0]), "=&v"(u[1])
-                 : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
-    float w = (b1 ? u[1] : u[0]) + xor2(b1 ? u[0] : u[1]);
-    w += xor1(w);
-    return w;
-}
-// 4 values: on return every lane of row r holds the wave-wide sum of x[r].
-__device__ __forceinline__ float reduce4_rows(float x0, float x1, float x2, float x3)
-{
-    GSR_SWAP2("v_permlane32_swap_b32", x0, x1, x2, x3);
-    float y0 = x0 + x2, y1 = x1 + x3;  // value (0|1) + 2*b5
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(y0), "+v"(y1));
-    float z = y0 + y1;                  // value b4 + 2*b5
-    z += xor1(z);
-    z += xor2(z);
-    z += dpp_mov<0x141, 0xf, 0xf>(0.f, z);  // row_half_mirror
-    z += dpp_mov<0x140, 0xf, 0xf>(0.f, z);  // row_mirror
-    return z;
-}
-
-// ---- self-test of the cross-lane reduction (gsr_selftest) ------------------------------------------------
-__global__ void k_selftest_reduce(float* out32, float* out4)
-{
-    const uint32_t lane = threadIdx.x;
-    float v[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) v[i] = (float)((lane + 1) * (i + 1));  // wave sum = (i+1) * 2080
-    out32[lane] = reduce32_transposed(v, lane);
-    out4[lane] = reduce4_rows((float)(lane + 1), (float)(2 * (lane + 1)), (float)(3 * (lane + 1)), (float)(4 * (lane + 1)));
-}
-
-int selftest_reduce(hipStream_t stream, float* d_scratch128)
-{
-    hipLaunchKernelGGL(k_selftest_reduce, dim3(1), dim3(64), 0, stream, d_scratch128, d_scratch128 + 64);
-    float h[128];
-    if (hipMemcpyAsync(h, d_scratch128, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
-    for (int l = 0; l < 64; l++) {
-        if (h[l] != (float)(((l >> 1) + 1) * 2080)) return 1 + l;
-        if (h[64 + l] != (float)(((l >> 4) + 1) * 2080)) return 101 + l;
-    }
-    return 0;
-}
-
 // ---- wave reduction on the matrix cores ------------------------------------------------------------------
 // The nine sums of an entry over the 64 pixels of a quadrant are a contraction over the pixel index:
 //   dL/d{mean2D, conic, opacity} are moments  sum_p q[e][p] * {1, cx, cy, cx^2, cx cy, cy^2}(p)  of ONE per-(entry, pixel)
@@ -203,12 +93,15 @@ int selftest_reduce(hipStream_t stream, float* d_scratch128)
 //   splat's own centre afterwards (dx = bx - cx with bx = mean.x - quadrant centre, a per-ENTRY constant);
 //   dL/dcolour[ch] = sum_p u[e][p] * dL_dpixel[ch][p] with u = alpha * T.
 // So a batch of 8 entries is a 16-row matrix (rows 0..7 q, rows 8..15 u) x 64 pixels, written to LDS by the lanes
-// that own the pixels and multiplied by a constant 64 x 16 basis with sixteen v_mfma_f32_16x16x4_f32 (exact fp32, on the
-// otherwise idle matrix pipe): D[i][j] = sum_p F[i][p] * data[j][p].  Basis rows i = 4 g + r are laid out so that the four
+// that own the pixels and multiplied by a constant 64 x 16 basis with sixteen v_mfma_f32_16x16x4_f32 (exact fp32): D[i][j] = sum_p F[i][p] * data[j][p].
+// (An fp32 MFMA does not run beside other waves' VALU work on this part -- scripts/probe/mfma_overlap_probe.hip: the two
+// add up -- so the contraction costs its ~40 cycles of SIMD time per instruction; that is still less than half of the
+// partial products + transposed butterfly it replaces, and it needs no cross-lane instruction.)  Basis rows i = 4 g + r are laid out so that the four
 // accumulator registers of a lane (g = lane >> 4, column j = lane & 15) hold everything ONE output needs:
 //   g = 0: 1, cx, cy, cx^2 -> conic.x, mean.x     g = 1: 1, cx, cy, cx cy -> conic.y, mean.y
 //   g = 2: 1, cx, cy, cy^2 -> conic.w, opacity    g = 3: dL_dpixel r, g, b -> colour (u columns only)
-// No cross-lane instruction is left.  K step s = 4 m + r covers pixel 16 m + 4 k + r (k = lane >> 4), so a lane's four
+// Apart from four DPP moves that spread an entry's nine values over nine lanes for the atomics, no cross-lane
+// instruction is left.  K step s = 4 m + r covers pixel 16 m + 4 k + r (k = lane >> 4), so a lane's four
 // ds_read_b128 of its row are the B operands of the sixteen steps.
 constexpr int MM_STRIDE = 68;   // floats per LDS row: 272 B, consecutive rows 4 banks apart (conflict-free b128 reads)
 
@@ -367,9 +260,6 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     a.grad_rec = at_view(a.grad_rec, a.gr_stride, view);
     a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
-#ifdef GSR_BWD_BUTTERFLY
-    __shared__ __attribute__((aligned(16))) float stage[16 * QUAD_WORDS];
-#else
     // group 16 keeps the entries of a batch that is still open when its round ends (the next round restages groups 0..15)
     __shared__ __attribute__((aligned(16))) float stage[17 * QUAD_WORDS];
     __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];   // 8 entries x {q, u} rows x 64 pixels
@@ -387,7 +277,6 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     const uint32_t mm_cB = mm_g < 3u ? (mm_j < 4u ? mm_c2 : 2u + mm_g) : (mm_j >= 12u ? 5u : mm_j >= 8u ? 6u : 7u);
     const uint32_t mm_offP = mm_g == 0 ? 8u : 12u, mm_offQ = mm_g == 0 ? 12u : 16u;   // conic A|B resp. B|C
     const float mm_dd = -(mm_g == 0 ? (float)(0.5 * a.W) : (float)(0.5 * a.H));
-#endif
 #ifdef GSR_STATS
     BW_T(tw0);
     unsigned long long tw_wait = 0, tw_setup = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_groups = 0, n_items_done = 0;
@@ -439,30 +328,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     bg_dot_dpixel += a.bg[0] * dpx0;
     bg_dot_dpixel += a.bg[1] * dpx1;
     bg_dot_dpixel += a.bg[2] * dpx2;
-#ifdef GSR_BWD_BUTTERFLY
-    const float ddelx_dx = (float)(0.5 * a.W);
-    const float ddely_dy = (float)(0.5 * a.H);
-#else
     mrow[lane] = dpx0; mrow[MM_STRIDE + lane] = dpx1; mrow[2 * MM_STRIDE + lane] = dpx2;
     mm_basis_dpx(am, mrow, lane);
     const float mm_sx = x0f + 3.5f, mm_sy = y0f + 3.5f;   // quadrant centre
-#endif
 
     // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3 of the group,
     // component c = i & 7 in {mean2D.x, mean2D.y, conic.x, conic.y, conic.w, colour r, g, b}; odd lanes 1, 17, 33, 49
     // own the opacity gradient (component 8) of entries 0..3.  target = grad_rec[id][c]: the nine atomics of an entry
     // fall into one 64-B line.
-#ifdef GSR_BWD_BUTTERFLY
-    int tgt_k = (int)(lane >> 4), tgt_c = 0;
-    bool tgt_on = false;
-    if ((lane & 1u) == 0) {
-        tgt_c = (int)((lane >> 1) & 7u);
-        tgt_on = true;
-    } else if ((lane & 15u) == 1) {
-        tgt_c = 8;
-        tgt_on = true;
-    }
-#endif
 
     // the staging area starts as zeros, so slots of a partly filled last group always hold finite values (their
     // opacity is set to 0 every round, which is what keeps them from ever hitting)
@@ -505,9 +378,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 #ifdef GSR_STATS
     { BW_T(ti1); tw_setup += ti1 - ti0; }
 #endif
-#ifndef GSR_BWD_BUTTERFLY
     uint32_t nb = 0, gq0 = 0, gq1 = 0;   // groups in the open batch (it may span rounds), their staging groups
-#endif
     for (int hi = hi0; hi > lo; hi -= 64) {
 #ifdef GSR_STATS
         BW_T(tr0);
@@ -552,9 +423,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         BW_T(tr1);
         tw_stage += tr1 - tr0;
 #endif
-#ifndef GSR_BWD_BUTTERFLY
         const bool last_round = hi - 64 <= lo;
-#endif
         for (;;) {
           const bool more = mask != 0;
           if (more) {
@@ -581,7 +450,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 mask = have ? (mask & (mask - 1)) : 0;
                 ef[k] = (uint32_t)(hi - 1 - j);  // 0-based position of the entry in the tile list
             }
-            float dxs[BGRP], dys[BGRP], Gs[BGRP], alphas[BGRP];
+            float Gs[BGRP], alphas[BGRP];
             bool hits[BGRP];
             bool any_lane_hit = false;
             // pairs of entries on float2: the arithmetic maps onto packed fp32 instructions (two IEEE operations per
@@ -594,7 +463,6 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 const f32x2 power = -0.5f * (A2 * dx * dx + C2 * dy * dy) - B2 * dx * dy;
                 const f32x2 G = bw_exp_nonpos2(power);
                 const f32x2 al = O2 * G;
-                dxs[k] = dx.x; dxs[k + 1] = dx.y; dys[k] = dy.x; dys[k + 1] = dy.y;
                 Gs[k] = G.x; Gs[k + 1] = G.y;
                 alphas[k] = fminf(0.99f, al.x);
                 alphas[k + 1] = fminf(0.99f, al.y);
@@ -643,7 +511,6 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 last_d = d;
                 last_alpha = alpha;
             }
-#ifndef GSR_BWD_BUTTERFLY
             // Phase 2 is two weights per (pixel, entry): q = G dL_dalpha and u = alpha T, one LDS row each; the sums over the
             // pixels are taken by the matrix cores once two groups have been written (mm_basis)
             {
@@ -658,47 +525,8 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 if (nb == 0) gq0 = (uint32_t)(quad - 1); else gq1 = (uint32_t)(quad - 1);
                 nb++;
             }
-#else
-            // Phase 2: the 4 x 9 partial derivatives of this lane's pixel, again on entry pairs
-            float v[32], xo[BGRP];
-#pragma unroll
-            for (int k = 0; k < BGRP; k += 2) {
-                const f32x2 dx = {dxs[k], dxs[k + 1]}, dy = {dys[k], dys[k + 1]};
-                const f32x2 O2 = {eo[k], eo[k + 1]}, A2 = {eA[k], eA[k + 1]}, B2 = {eB[k], eB[k + 1]}, C2 = {eC[k], eC[k + 1]};
-                const f32x2 dLa2 = {dLa[k], dLa[k + 1]}, Gh2 = {Gh[k], Gh[k + 1]}, dch2 = {dch[k], dch[k + 1]};
-                const f32x2 dL_dG = O2 * dLa2;
-                const f32x2 gdx = Gh2 * dx, gdy = Gh2 * dy;
-                const f32x2 dG_ddelx = -__builtin_elementwise_fma(gdx, A2, gdy * B2);
-                const f32x2 dG_ddely = -__builtin_elementwise_fma(gdy, C2, gdx * B2);
-                const f32x2 h = -0.5f * dL_dG;
-                const f32x2 m0 = dL_dG * dG_ddelx * ddelx_dx, m1 = dL_dG * dG_ddely * ddely_dy;
-                const f32x2 c0v = h * gdx * dx, c1v = h * gdx * dy, c3v = h * gdy * dy;
-                const f32x2 k0 = dch2 * dpx0, k1 = dch2 * dpx1, k2 = dch2 * dpx2;
-                const f32x2 op = Gh2 * dLa2;
-                v[8 * k + 0] = m0.x; v[8 * k + 8] = m0.y;
-                v[8 * k + 1] = m1.x; v[8 * k + 9] = m1.y;
-                v[8 * k + 2] = c0v.x; v[8 * k + 10] = c0v.y;
-                v[8 * k + 3] = c1v.x; v[8 * k + 11] = c1v.y;
-                v[8 * k + 4] = c3v.x; v[8 * k + 12] = c3v.y;
-                v[8 * k + 5] = k0.x; v[8 * k + 13] = k0.y;
-                v[8 * k + 6] = k1.x; v[8 * k + 14] = k1.y;
-                v[8 * k + 7] = k2.x; v[8 * k + 15] = k2.y;
-                xo[k] = op.x; xo[k + 1] = op.y;
-            }
-            // reduce over the 64 pixels, then one atomic instruction for the whole group
-            const float w = reduce32_transposed(v, lane);
-            const float z = reduce4_rows(xo[0], xo[1], xo[2], xo[3]);
-            const float val = (lane & 1u) ? z : w;
-            // this lane's entry id, straight from the id row of the group
-            const uint32_t id = __builtin_bit_cast(uint32_t, stage[(quad - 1) * QUAD_WORDS + 36 + tgt_k]);
-            if (tgt_on && val != 0.f) atomicAdd(a.grad_rec + (size_t)id * GRAD_REC_WORDS + tgt_c, val);
-#endif
             }   // any lane hit
           }     // more
-#ifndef GSR_BWD_BUTTERFLY
-#ifdef GSR_X_NOFLUSH
-          if (nb == 2u) nb = 0;
-#else
           if (nb == 2u || (!more && nb != 0u && last_round)) {
             // per-entry constants and targets first: their LDS round trips pass while the matrix pipe works
             const float* e = stage + (mm_gb ? gq1 : gq0) * QUAD_WORDS + mm_k4;
@@ -707,12 +535,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
             // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
-#ifdef GSR_X_NOMFMA
-            const f32x4* rp_ = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
-            const f32x4 acc = rp_[0] + rp_[4] + rp_[8] + rp_[12];
-#else
             const f32x4 acc = mm_contract(mrow, am, lane);
-#endif
             const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
             const float S1 = acc.x, Sx = acc.y, Sy = acc.z, V3 = acc.w;
             const float Dx = __builtin_fmaf(bx, S1, -Sx), Dy = __builtin_fmaf(by, S1, -Sy);   // sum q dx, sum q dy
@@ -732,25 +555,17 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             vA = dpp_mov<0x128, 0x8, 0x1>(vA, o3);         // row_ror:8, row 3 bank 0: colour b of lane + 8
             float vB = dpp_mov<0x104, 0xf, 0x5>(o1, o2);   // row_shl:4 -> banks 0, 2: o2 of the lane four above
             vB = dpp_mov<0x128, 0x8, 0x2>(vB, o3);         // row 3 bank 1: colour b of lane + 8
-#ifndef GSR_X_NOATOM
             if (mm_onA && vA != 0.f) atomicAdd(a.grad_rec + (size_t)idA * GRAD_REC_WORDS + mm_cA, vA);
             if (mm_onB && nb == 2u && vB != 0.f) atomicAdd(a.grad_rec + (size_t)idB * GRAD_REC_WORDS + mm_cB, vB);
-#else
-            if (vA + vB + __builtin_bit_cast(float, idA + idB) == 123.456f) a.grad_rec[0] = 1.f;
-#endif
             nb = 0;
           }
-#endif
-#endif
           if (!more) break;
         }
-#ifndef GSR_BWD_BUTTERFLY
         // a half-filled batch waits for the next round's first group: keep its entries' constants out of the restaging's way
         if (nb == 1u && gq0 != 16u) {
             if (lane < (uint32_t)QUAD_WORDS) stage[16 * QUAD_WORDS + lane] = stage[gq0 * QUAD_WORDS + lane];
             gq0 = 16u;
         }
-#endif
 #ifdef GSR_STATS
         BW_T(tr2);
         tw_eval += tr2 - tr1;

@@ -17,10 +17,11 @@ else:
     # the loop ends at the last branch back to the first label
     i1 = max(i for i, l in enumerate(body) if re.search(r"s_cbranch\w*\s+" + re.escape(first) + r"\b", l) or re.search(r"s_branch\s+" + re.escape(first) + r"\b", l)) + 1
 COST = {"pk_f32": 1.9, "valu_f32": 1.05, "valu_int": 1.05, "trans": 3.5, "dpp": 1.9, "permlane": 3.4, "cndmask": 1.9, "cmp": 1.9,
-        "mov": 1.05, "cvt_ldexp_rndne": 1.9, "salu": 0.0, "s_nop": 0.0, "s_waitcnt": 0.0, "lds": 0.0, "vmem": 0.0, "branch": 0.0, "minmax": 1.9}
+        "mov": 1.05, "cvt_ldexp_rndne": 1.9, "mfma_f32": 19.6, "salu": 0.0, "s_nop": 0.0, "s_waitcnt": 0.0, "lds": 0.0, "vmem": 0.0, "branch": 0.0, "minmax": 1.9}
 
 
 def classify(op, rest):
+    if op.startswith("v_mfma"): return "mfma_f32"   # 16x16x4 f32 among VALU work: 19.6 ns (13.7 back to back), mfma_overlap_probe
     if op.startswith("v_permlane"): return "permlane"
     if "dpp" in op or "row_" in rest or "quad_perm" in rest: return "dpp"
     if op.startswith("v_pk_") and "f32" in op: return "pk_f32"
