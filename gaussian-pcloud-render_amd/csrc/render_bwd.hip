@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 #ifdef GSR_STATS
     { BW_T(ti1); tw_setup += ti1 - ti0; }
 #endif
-    uint32_t nb = 0, gq0 = 0, gq1 = 0;   // groups in the open batch (it may span rounds), their staging groups
+    uint32_t nb = 0, gq0 = 0;   // groups in the open batch (it may span rounds), the staging group of its first one
     for (int hi = hi0; hi > lo; hi -= 64) {
 #ifdef GSR_STATS
         BW_T(tr0);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 hits[k + 1] = (ef[k + 1] < last_contributor) && !(power.y > 0.0f) && !(alphas[k + 1] < 1.0f / 255.0f);
                 any_lane_hit = any_lane_hit || hits[k] || hits[k + 1];
             }
-            if (__any(any_lane_hit)) {
+            if (__builtin_amdgcn_ballot_w64(any_lane_hit) != 0) {
 #if defined(GSR_STATS) && defined(GSR_STATS_HITS)
             BWD_STAT(3, 1);
             for (int k = 0; k < BGRP; k++) {
@@ -522,13 +522,14 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                     rq[k * MM_STRIDE] = op.x; rq[(k + 1) * MM_STRIDE] = op.y;
                     rq[(8 + k) * MM_STRIDE] = dch[k]; rq[(9 + k) * MM_STRIDE] = dch[k + 1];
                 }
-                if (nb == 0) gq0 = (uint32_t)(quad - 1); else gq1 = (uint32_t)(quad - 1);
+                if (nb == 0) gq0 = (uint32_t)(quad - 1);   // (a second group is flushed at once: it is group quad - 1 then)
                 nb++;
             }
             }   // any lane hit
           }     // more
           if (nb == 2u || (!more && nb != 0u && last_round)) {
             // per-entry constants and targets first: their LDS round trips pass while the matrix pipe works
+            const uint32_t gq1 = (uint32_t)(quad > 0 ? quad - 1 : 0);   // the batch's second group, if it has one, was evaluated just now
             const float* e = stage + (mm_gb ? gq1 : gq0) * QUAD_WORDS + mm_k4;
             const float eX = e[0], eY = e[4], cP = e[mm_offP], cQ = e[mm_offQ], cO = e[20];
             const uint32_t idA = __builtin_bit_cast(uint32_t, stage[gq0 * QUAD_WORDS + 36u + mm_k4]);
