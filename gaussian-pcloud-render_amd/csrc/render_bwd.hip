@@ -101,17 +101,25 @@ __device__ __forceinline__ float dpp_mov(float old, float v)
 //   g = 0: 1, cx, cy, cx^2 -> conic.x, mean.x     g = 1: 1, cx, cy, cx cy -> conic.y, mean.y
 //   g = 2: 1, cx, cy, cy^2 -> conic.w, opacity    g = 3: dL_dpixel r, g, b -> colour (u columns only)
 // Apart from four DPP moves that spread an entry's nine values over nine lanes for the atomics, no cross-lane
-// instruction is left.  K step s = 4 m + r covers pixel 16 m + 4 k + r (k = lane >> 4), so a lane's four
-// ds_read_b128 of its row are the B operands of the sixteen steps.
+// instruction is left.  A row stores the pixels in 2x2-block order (mm_pos): K step s = 4 m + r covers row positions
+// 16 m + 4 k + r (k = lane >> 4) = the four pixels of block (column pair r, row pair m), so a lane's four ds_read_b128 of
+// its row are the B operands of the sixteen steps, and a step whose block no entry of the batch hits multiplies zeros
+// and is skipped (12 of 16 blocks are hit per batch on the benchmark views; worth 1.7 % of the kernel).
 constexpr int MM_STRIDE = 68;   // floats per LDS row: 272 B, consecutive rows 4 banks apart (conflict-free b128 reads)
 
+// position of pixel (lane = 8 y + x) in an LDS row: 16 (y >> 1) + 4 ((x & 1) + 2 (y & 1)) + (x >> 1)
+__device__ __forceinline__ uint32_t mm_pos(uint32_t lane)
+{
+    const uint32_t x = lane & 7u, y = lane >> 3;
+    return 16u * (y >> 1) + 4u * ((x & 1u) + 2u * (y & 1u)) + (x >> 1);
+}
 __device__ __forceinline__ void mm_basis(float (&am)[16], uint32_t lane)
 {
     const uint32_t i = lane & 15u, k = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-        const uint32_t p = 16u * (uint32_t)(s >> 2) + 4u * k + (uint32_t)(s & 3);
-        const float cx = (float)(p & 7u) - 3.5f, cy = (float)(p >> 3) - 3.5f;
+        // step s = 4 m + r, operand lane group k: pixel x = 2 r + (k & 1), y = 2 m + (k >> 1)
+        const float cx = (float)(2u * (uint32_t)(s & 3) + (k & 1u)) - 3.5f, cy = (float)(2u * (uint32_t)(s >> 2) + (k >> 1)) - 3.5f;
         const uint32_t c = i & 3u;
         const float f = c == 0 ? 1.f : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
         am[s] = i < 12u ? f : 0.f;
@@ -130,17 +138,18 @@ __device__ __forceinline__ void mm_basis_dpx(float (&am)[16], const float* mrow,
         }
     }
 }
-__device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am)[16], uint32_t lane)
+// `blocks`: bit 16 m + 2 r set = some row is non-zero in 2x2 block (r, m) (a superset is fine)
+__device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am)[16], uint32_t lane, unsigned long long blocks)
 {
     const f32x4* rp = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const f32x4 b = rp[4 * m];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 0], b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 1], b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 2], b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 3], b.w, acc, 0, 0, 0);
+        if ((blocks >> (16 * m + 0)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 0], b.x, acc, 0, 0, 0);
+        if ((blocks >> (16 * m + 2)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 1], b.y, acc, 0, 0, 0);
+        if ((blocks >> (16 * m + 4)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 2], b.z, acc, 0, 0, 0);
+        if ((blocks >> (16 * m + 6)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 3], b.w, acc, 0, 0, 0);
     }
     return acc;
 }
@@ -152,11 +161,14 @@ __global__ void k_selftest_mm(float* out256)
     float am[16];
     mm_basis(am, lane);
     // "dL_dpixel" of pixel p, channel c: ((p + 2 c) % 5) - 2
-    for (int c = 0; c < 3; c++) mrow[c * MM_STRIDE + lane] = (float)((int)((lane + 2u * c) % 5u) - 2);
+    const uint32_t pos = mm_pos(lane);
+    for (int c = 0; c < 3; c++) mrow[c * MM_STRIDE + pos] = (float)((int)((lane + 2u * c) % 5u) - 2);
     mm_basis_dpx(am, mrow, lane);
     // data[j][p] = ((7 j + 3 p) % 11) - 5: small integers, every sum exact
-    for (int j = 0; j < 16; j++) mrow[j * MM_STRIDE + lane] = (float)((int)((7u * j + 3u * lane) % 11u) - 5);
-    const f32x4 acc = mm_contract(mrow, am, lane);
+    // (pixels of the 2x2 blocks (3, 0) and (1, 2) are zero in every row: those two steps are skipped)
+    const bool hole = ((lane & 7u) >> 1 == 3u && (lane >> 4) == 0u) || ((lane & 7u) >> 1 == 1u && (lane >> 4) == 2u);
+    for (int j = 0; j < 16; j++) mrow[j * MM_STRIDE + pos] = hole ? 0.f : (float)((int)((7u * j + 3u * lane) % 11u) - 5);
+    const f32x4 acc = mm_contract(mrow, am, lane, ~((1ull << 6) | (1ull << 34)));
     out256[lane * 4 + 0] = acc.x; out256[lane * 4 + 1] = acc.y; out256[lane * 4 + 2] = acc.z; out256[lane * 4 + 3] = acc.w;
 }
 
@@ -175,7 +187,8 @@ int selftest_mm(hipStream_t stream, float* d_scratch256)
                 const int c = i & 3;
                 double f = c == 0 ? 1. : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
                 if (i >= 12) f = i < 15 ? (double)((p + 2 * (i - 12)) % 5 - 2) : 0.;
-                want += f * (double)((7 * j + 3 * p) % 11 - 5);
+                const bool hole = (((p & 7) >> 1) == 3 && (p >> 4) == 0) || (((p & 7) >> 1) == 1 && (p >> 4) == 2);
+                want += hole ? 0. : f * (double)((7 * j + 3 * p) % 11 - 5);
             }
             if ((double)h[l * 4 + r] != want) return 1 + l * 4 + r;
         }
@@ -185,7 +198,7 @@ int selftest_mm(hipStream_t stream, float* d_scratch256)
 #if defined(GSR_STATS) && defined(GSR_STATS_HITS)
 // instrumentation build only (GSR_EXTRA_FLAGS="-DGSR_STATS -DGSR_STATS_HITS"; the atomics slow the kernel 100x, so they are
 // kept out of the timing build): 0 rounds, 1 staged entries, 2 groups, 3 groups with a hit,
-// 4 entries with a hit, 5 (pixel, entry) hits
+// 4 entries with a hit, 5 (pixel, entry) hits, 6 batches flushed, 7 2x2 pixel blocks hit per batch (summed)
 __device__ unsigned long long g_bwd_stats[8];
 #define BWD_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bwd_stats[i], (unsigned long long)(v)); } while (0)
 #else
@@ -265,6 +278,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];   // 8 entries x {q, u} rows x 64 pixels
     float am[16];                                                          // A operands of the 16 K steps (basis)
     mm_basis(am, threadIdx.x);
+    const uint32_t mm_p = mm_pos(threadIdx.x);                              // this lane's pixel in a row
     // what this lane does with its four accumulator values after a batch's contraction (see mm_basis): g < 3 on q columns,
     // g = 3 on u columns
     const uint32_t mm_g = threadIdx.x >> 4, mm_j = threadIdx.x & 15u;
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     bg_dot_dpixel += a.bg[0] * dpx0;
     bg_dot_dpixel += a.bg[1] * dpx1;
     bg_dot_dpixel += a.bg[2] * dpx2;
-    mrow[lane] = dpx0; mrow[MM_STRIDE + lane] = dpx1; mrow[2 * MM_STRIDE + lane] = dpx2;
+    mrow[mm_p] = dpx0; mrow[MM_STRIDE + mm_p] = dpx1; mrow[2 * MM_STRIDE + mm_p] = dpx2;
     mm_basis_dpx(am, mrow, lane);
     const float mm_sx = x0f + 3.5f, mm_sy = y0f + 3.5f;   // quadrant centre
 
@@ -378,6 +392,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 #ifdef GSR_STATS
     { BW_T(ti1); tw_setup += ti1 - ti0; }
 #endif
+    unsigned long long hit_px = 0;   // pixels hit by some entry of the open batch
     uint32_t nb = 0, gq0 = 0;   // groups in the open batch (it may span rounds), the staging group of its first one
     for (int hi = hi0; hi > lo; hi -= 64) {
 #ifdef GSR_STATS
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             // Phase 2 is two weights per (pixel, entry): q = G dL_dalpha and u = alpha T, one LDS row each; the sums over the
             // pixels are taken by the matrix cores once two groups have been written (mm_basis)
             {
-                float* rq = mrow + nb * 4u * MM_STRIDE + lane;
+                float* rq = mrow + nb * 4u * MM_STRIDE + mm_p;
 #pragma unroll
                 for (int k = 0; k < BGRP; k += 2) {
                     const f32x2 dLa2 = {dLa[k], dLa[k + 1]}, Gh2 = {Gh[k], Gh[k + 1]};
@@ -522,12 +537,18 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                     rq[k * MM_STRIDE] = op.x; rq[(k + 1) * MM_STRIDE] = op.y;
                     rq[(8 + k) * MM_STRIDE] = dch[k]; rq[(9 + k) * MM_STRIDE] = dch[k + 1];
                 }
+                hit_px = (nb == 0 ? 0ull : hit_px) | __builtin_amdgcn_ballot_w64(any_lane_hit);
                 if (nb == 0) gq0 = (uint32_t)(quad - 1);   // (a second group is flushed at once: it is group quad - 1 then)
                 nb++;
             }
             }   // any lane hit
           }     // more
           if (nb == 2u || (!more && nb != 0u && last_round)) {
+            // 2x2 pixel blocks that some entry of the batch hits (bit 16 (y >> 1) + 2 (x >> 1)): the others are zero in all rows
+            unsigned long long hit_blocks = hit_px | (hit_px >> 1);
+            hit_blocks |= hit_blocks >> 8;
+            BWD_STAT(6, 1);                                                   // batches flushed
+            BWD_STAT(7, __popcll(hit_blocks & 0x0055005500550055ull));        // blocks hit (of 16 per batch)
             // per-entry constants and targets first: their LDS round trips pass while the matrix pipe works
             const uint32_t gq1 = (uint32_t)(quad > 0 ? quad - 1 : 0);   // the batch's second group, if it has one, was evaluated just now
             const float* e = stage + (mm_gb ? gq1 : gq0) * QUAD_WORDS + mm_k4;
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
             // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
-            const f32x4 acc = mm_contract(mrow, am, lane);
+            const f32x4 acc = mm_contract(mrow, am, lane, hit_blocks);
             const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
             const float S1 = acc.x, Sx = acc.y, Sy = acc.z, V3 = acc.w;
             const float Dx = __builtin_fmaf(bx, S1, -Sx), Dy = __builtin_fmaf(by, S1, -Sy);   // sum q dx, sum q dy

@@ -21,3 +21,5 @@ for vid in (0, 3):
     r, st, gr, grh, eh, ph = [int(x) for x in out[:6]]
     print("view %d: rounds %d staged entries %d (%.1f / round) groups %d with-hit %d (%.0f%%) entries-with-hit %d (%.0f%% of staged) pixel-hits %d (%.1f per hit entry)"
           % (vid, r, st, st / max(r, 1), gr, grh, 100.0 * grh / max(gr, 1), eh, 100.0 * eh / max(st, 1), ph, ph / max(eh, 1)))
+    print("        batches flushed %d (%.2f groups per batch), 2x2 pixel blocks hit by some entry of the batch: %.2f of 16"
+          % (int(out[6]), grh / max(int(out[6]), 1), int(out[7]) / max(int(out[6]), 1)))
