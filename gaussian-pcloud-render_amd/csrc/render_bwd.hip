@@ -254,6 +254,9 @@ struct RenderBwdArgs {
     size_t g_stride, b_stride, iv_stride, gr_stride;
 };
 
+// five waves per SIMD: 96 registers (the accumulator in VGPRs, five values of the item set-up spilled outside the hot
+// loops); the loop runs at ~70 % of the vector pipe with four waves, a fifth is worth 2.6 %
+__attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
     // Work items are (tile, chunk of BWD_CHUNK consumed list entries); a workgroup takes every (gridDim/32 * 8)-th item.
