@@ -116,6 +116,9 @@ def test_random_case_matches_reference_build(i, gpu_device):
         if n4:
             used_4x = True
             TALLY["rows_exit_4x_reference"] += n4
+            w = np.nonzero(ok & ~plain)[0]
+            print("fuzz exit (4x reference): case %d %s rows %s: lib-exact %s, ref-exact %s, row bar %s" % (
+                i, k, w.tolist()[:4], r_lib[w][:4], r_build[w][:4], (util.ROW_REL * rn + util.ROW_ABS * rn.max())[w][:4]))
         if not ok.all() and k in ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
             # Still outside: is the row simply that ill-conditioned?  (a) The render-level sums every float32 implementation
             # feeds into the chain carry ~1e-6 of relative rounding noise: push noise of that size through the float64 chain
