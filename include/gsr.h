@@ -192,7 +192,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
 void gsr_set_profiling(int on);
 int gsr_get_profile(const char** names, float* ms, int cap);
 
-/* Device self-test of internal primitives (wave reduction of the backward pass, stable radix sort vs std::stable_sort).
+/* Device self-test of internal primitives (the matrix-core pixel contraction of the render backward, stable radix sort vs std::stable_sort).
  * Allocates its own small buffers; not part of the hot path.  0 = pass. */
 int gsr_selftest(gsr_stream_t stream);
 

@@ -142,7 +142,7 @@ def test_determinism_of_forward(gpu_device):
 
 
 def test_library_selftest_of_internal_primitives(gpu_device):
-    """Transposed wave64 reduction (v_permlane swaps + DPP) and the stable radix sort vs std::stable_sort."""
+    """The matrix-core pixel contraction of the render backward (operand layout, block skipping) and the stable radix sort vs std::stable_sort."""
     from diff_gaussian_rasterization import _native as N
     N.selftest(gpu_device)
 
