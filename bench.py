@@ -42,6 +42,8 @@ import time
 # (default 4) hardware queues, and with four worker streams plus the stream the frames are gathered on, two of them end
 # up sharing one queue and serialise (measured: 800 vs 900 frames/s on the same box).  Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL / cross-process device memory on this pool needs dmabuf IPC (the image exports it already; kept for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "gaussian-pcloud-render_amd"), os.path.join(ROOT, "tests")):
