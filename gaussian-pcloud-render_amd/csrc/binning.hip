@@ -295,12 +295,16 @@ __device__ __forceinline__ uint32_t lower_bound_keys(const KeyT* __restrict__ ke
     return lo;
 }
 
+// A workgroup of 256 threads serves 255 tiles: thread i finds the lower bound of tile t0 + i, thread 255 the one that closes
+// the last tile's list; a tile's range is (its bound, its neighbour's) -- one search per thread instead of two.
+constexpr int RANGE_TILES_PER_WG = 255;
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict__ counters, size_t g_stride, int64_t cap,
                                                      const KeyT* __restrict__ keys, size_t b_stride, uint2* __restrict__ ranges,
                                                      size_t iv_stride, int T)
 {
     __shared__ uint32_t samples[RANGE_MAX_SAMPLES];
+    __shared__ uint32_t bound[256];
     const uint32_t view = blockIdx.y;
     const uint64_t n64 = at_view(counters, g_stride, view)[CNT_NUM_RENDERED];
     const uint32_t n = (uint32_t)(n64 < (uint64_t)cap ? n64 : (uint64_t)cap);
@@ -310,19 +314,17 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict_
     if (ns > RANGE_MAX_SAMPLES) ns = 0;   // enormous lists: plain binary search
     for (uint32_t j = threadIdx.x; j < ns; j += 256) samples[j] = (uint32_t)keys[(size_t)j * RANGE_SAMPLE];
     __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    uint2 r = make_uint2(0u, 0u);
-    if (n != 0) {
-        const uint32_t first = lower_bound_keys(keys, n, samples, ns, (uint32_t)t);
-        if (first < n && (uint32_t)keys[first] == (uint32_t)t) r = make_uint2(first, lower_bound_keys(keys, n, samples, ns, (uint32_t)t + 1u));
-    }
-    ranges[t] = r;
+    const int t = blockIdx.x * RANGE_TILES_PER_WG + threadIdx.x;
+    bound[threadIdx.x] = (t < T && n != 0) ? lower_bound_keys(keys, n, samples, ns, (uint32_t)t) : n;   // tile ids are < T: bound(T) = n
+    __syncthreads();
+    if (threadIdx.x >= RANGE_TILES_PER_WG || t >= T) return;
+    const uint32_t first = bound[threadIdx.x], last = bound[threadIdx.x + 1];
+    ranges[t] = first < last ? make_uint2(first, last) : make_uint2(0u, 0u);
 }
 
 int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16)
 {
-    const dim3 grid((unsigned)div_up(T, 256), B.V);
+    const dim3 grid((unsigned)div_up(T, RANGE_TILES_PER_WG), B.V);
     if (key16)
         hipLaunchKernelGGL(k_tile_ranges<uint16_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap,
                            (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride, T);
