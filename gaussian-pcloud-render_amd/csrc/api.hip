@@ -599,6 +599,7 @@ int gsr_get_profile(const char** names, float* ms, int cap)
 __attribute__((visibility("default"))) int gsr_debug_bwd_stats(unsigned long long* out8, int reset) { return gsr::debug_bwd_stats(out8, reset); }
 __attribute__((visibility("default"))) int gsr_debug_scatter_times(unsigned long long* out8, int reset) { return gsr::debug_scatter_times(out8, reset); }
 __attribute__((visibility("default"))) int gsr_debug_fwd_times(unsigned long long* out8, int reset) { return gsr::debug_fwd_times(out8, reset); }
+__attribute__((visibility("default"))) int gsr_debug_fwd_records(unsigned* out, int n) { return gsr::debug_fwd_records(out, n); }
 __attribute__((visibility("default"))) int gsr_debug_bwd_times(unsigned long long* out8, int reset) { return gsr::debug_bwd_times(out8, reset); }
 __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long long* out8, int reset) { return gsr::debug_dup_times(out8, reset); }
 #endif

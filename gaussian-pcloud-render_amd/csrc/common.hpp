@@ -293,6 +293,7 @@ int debug_bwd_stats(unsigned long long* out8, int reset);   // instrumentation b
 int debug_dup_times(unsigned long long* out8, int reset);
 int debug_scatter_times(unsigned long long* out8, int reset);
 int debug_fwd_times(unsigned long long* out8, int reset);
+int debug_fwd_records(unsigned* out, int n);
 int debug_bwd_times(unsigned long long* out8, int reset);
 #endif
 // preprocess_bwd.hip

@@ -160,6 +160,20 @@ __device__ __forceinline__ PairRec<NX> read_pair(const float* lds, int pair)
 // (one record per wave of the LAST launch -- same-address atomics from 390 K waves would be what gets measured)
 constexpr int FW_REC = 1 << 19;
 __device__ unsigned g_fwd_rec[FW_REC][8];
+__device__ unsigned g_fwd_hw[FW_REC][2];   // where and when each wave ran: HW_ID | XCC_ID << 28, start tick (low 32 bits)
+// raw per-wave records of the last launch, ten words per wave (scripts/debug/fwd_placement.py)
+int debug_fwd_records(unsigned* out, int n)
+{
+    static unsigned host[FW_REC][8], hw[FW_REC][2];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_rec), sizeof(host)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_fwd_hw), sizeof(hw)) != hipSuccess) return -1;
+    if (n > FW_REC) n = FW_REC;
+    for (int r = 0; r < n; r++) {
+        for (int i = 0; i < 8; i++) out[r * 10 + i] = host[r][i];
+        out[r * 10 + 8] = hw[r][0]; out[r * 10 + 9] = hw[r][1];
+    }
+    return n;
+}
 #define FW_T(var) const unsigned long long var = wall_clock64()
 int debug_fwd_times(unsigned long long* out8, int reset)
 {
@@ -464,6 +478,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         unsigned* r_ = g_fwd_rec[blockIdx.x];
         r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_stage; r_[3] = (unsigned)tw_eval;
         r_[4] = 1u; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_pairs;
+        g_fwd_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492) | (__builtin_amdgcn_s_getreg(63508) << 28);   // HW_ID, XCC_ID
+        g_fwd_hw[blockIdx.x][1] = (unsigned)tw0;
     }
 #endif
     // instrumentation: how many list entries this tile really needed (max over its pixels); tile_need is zeroed
