@@ -77,6 +77,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     __shared__ uint32_t s_off[4][64];
     __shared__ uint32_t s_id[4][64];
     __shared__ uint2 s_rect[4][64];
+    __shared__ uint32_t s_flag[4][64];
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_base;
     __shared__ uint32_t s_ticket;
@@ -212,28 +213,46 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
         const uint32_t grp_begin = (uint32_t)grp_begin64;
         const uint32_t grp_end = grp_end64 < (uint64_t)a.cap ? (uint32_t)grp_end64 : (uint32_t)a.cap;   // cap < 2^32
         // offsets relative to the group's begin (fit 32 bits: 64 Gaussians x < 2^28 tiles is rejected by the host long before)
+        // The Gaussians that emit at least one pair are compacted (their offsets are then strictly increasing), and every
+        // chunk of 64 output slots finds its owners without a search: the owners whose run STARTS inside the chunk raise a
+        // flag at their first slot (distinct slots: plain LDS stores), one ballot of the flags gives the chunk's start mask,
+        // and slot l belongs to Gaussian number (starts before the chunk) + (starts at slots <= l) - 1.  Two LDS round trips
+        // per 64 pairs instead of the eight of a binary search over the offsets.
+        const uint64_t nzb = __ballot(cnt_g != 0);
+        const uint32_t n_nz = (uint32_t)__popcll(nzb);
+        const uint32_t jslot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, 0u));
         __builtin_amdgcn_wave_barrier();   // the previous group's reads of the staging arrays are done
-        s_off[w][lane] = (uint32_t)(off64 - grp_begin64);
-        s_id[w][lane] = id_g;
-        s_rect[w][lane] = rc_g;
+        if (cnt_g != 0) {
+            s_off[w][jslot] = (uint32_t)(off64 - grp_begin64);
+            s_id[w][jslot] = id_g;
+            s_rect[w][jslot] = rc_g;
+        }
         __builtin_amdgcn_wave_barrier();
-
-        for (uint32_t p = grp_begin + lane; p < grp_end; p += 64) {
-            const uint32_t rel = p - grp_begin;
-            // largest s with s_off[s] <= rel  (offsets are non-decreasing; zero-count entries are skipped)
-            uint32_t lo = 0;
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const uint32_t cand = lo + step;
-                if (cand < 64 && s_off[w][cand] <= rel) lo = cand;
+        const uint32_t my_start = lane < n_nz ? s_off[w][lane] : 0xFFFFFFFFu;   // first slot of the lane-th emitting Gaussian
+        const uint32_t range = grp_end - grp_begin;
+        uint32_t before = 0;                                                    // runs that start before the chunk
+        for (uint32_t c = 0; c < range; c += 64) {
+            s_flag[w][lane] = 0u;
+            const uint32_t d = my_start - c;
+            if (d < 64u) s_flag[w][d] = 1u;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t mine = s_flag[w][lane];
+            const uint64_t starts = __ballot(mine != 0u);
+            const uint32_t owner = before + mine - 1u +
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+            before += (uint32_t)__popcll(starts);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rel = c + lane;
+            if (rel < range) {
+                const uint2 r = s_rect[w][owner];
+                const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
+                const uint32_t width = maxx - minx;
+                const uint32_t t = rel - s_off[w][owner];
+                const uint32_t row = t / width, col = t - row * width;
+                const uint32_t p = grp_begin + rel;
+                keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
+                vals[p] = s_id[w][owner];
             }
-            const uint2 r = s_rect[w][lo];
-            const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
-            const uint32_t width = maxx - minx;
-            const uint32_t t = rel - s_off[w][lo];
-            const uint32_t row = t / width, col = t - row * width;
-            keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
-            vals[p] = s_id[w][lo];
         }
     }
 #ifdef GSR_STATS
