@@ -309,8 +309,10 @@ def main():
         for name, st in (("one_stream", 1), ("four_streams", 4)):
             if st > len(leafsets):
                 continue
-            run_steps(warm, 12, streams=st, vpc=1, gather_on=False)
-            drop_in["frames_per_s"][name] = round(48 / timed(48, streams=st, vpc=1), 1)
+            # every worker stream has to grow its own allocator pool and arenas first: 48 untimed frames, then the median of
+            # three blocks of 48 (a single cold block of 48 frames reported 410-700 frames/s for what runs at 1 400)
+            run_steps(warm, 48, streams=st, vpc=1, gather_on=False)
+            drop_in["frames_per_s"][name] = round(48 / float(np.median([timed(48, streams=st, vpc=1) for _ in range(3)])), 1)
         pv_ms, _ = stage_pass(24, vpc=1)
         drop_in["kernels_ms_per_frame"] = {k: round(v, 4) for k, v in pv_ms.items()}
         drop_in["kernel_sum_ms_per_frame"] = round(sum(pv_ms.values()), 4)
