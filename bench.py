@@ -320,8 +320,9 @@ def main():
         # ---- inference (forward only), both call shapes
         if grad:
             run_steps(warm, 2 * VPC, with_grad=False, gather_on=False)
-            fwd_only = {"views_per_call_%d_frames_per_s" % VPC: round(4 * VPC / timed(4 * VPC, with_grad=False), 1),
-                        "per_view_call_frames_per_s": round(48 / timed(48, streams=1, vpc=1, with_grad=False), 1)}
+            med3 = lambda n, **kw: float(np.median([timed(n, **kw) for _ in range(3)]))   # noqa: E731
+            fwd_only = {"views_per_call_%d_frames_per_s" % VPC: round(4 * VPC / med3(4 * VPC, with_grad=False), 1),
+                        "per_view_call_frames_per_s": round(48 / med3(48, streams=1, vpc=1, with_grad=False), 1)}
         # ---- the reference's own timing hook: `rgb time` = 12 views x (512^2 camera, super-sample 2 -> 1024^2 raster), SH pass,
         # per-view settings construction and the bilinear down-filter INSIDE the timed region (simple_raw_render.py:433-456)
         try:
