@@ -102,13 +102,17 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--cpu-frames", type=int, default=5, help="frames of the all-core CPU baseline (after 1 warm-up)")
     ap.add_argument("--no-cpu-1core", action="store_true", help="skip the 1-core CPU figure (about a minute of CPU time)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "2")),
-                    help="host threads per rank, each rendering whole submissions on its own HIP stream (views are independent)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "0")),
+                    help="host threads per rank, each rendering whole submissions on its own HIP stream (views are independent); "
+                         "0 = 2 when a timed block holds at least four submissions, else 1 (a second submission in flight is worth "
+                         "+1 %% on long blocks and costs 5 %% on a block of two submissions: the batched kernels have no tail to hide)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 lets several ranks share one GPU to exercise the multi-rank control flow "
                          "(frames then travel through host memory; not a performance mode)")
     ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
+    if args.streams <= 0:
+        args.streams = 2 if args.steps >= 4 * max(1, args.views_per_call) else 1
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
