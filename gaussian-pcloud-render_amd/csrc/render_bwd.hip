@@ -93,10 +93,11 @@ __device__ __forceinline__ float dpp_mov(float old, float v)
 //   splat's own centre afterwards (dx = bx - cx with bx = mean.x - quadrant centre, a per-ENTRY constant);
 //   dL/dcolour[ch] = sum_p u[e][p] * dL_dpixel[ch][p] with u = alpha * T.
 // So a batch of 8 entries is a 16-row matrix (rows 0..7 q, rows 8..15 u) x 64 pixels, written to LDS by the lanes
-// that own the pixels and multiplied by a constant 64 x 16 basis with sixteen v_mfma_f32_16x16x4_f32 (exact fp32): D[i][j] = sum_p F[i][p] * data[j][p].
-// (An fp32 MFMA does not run beside other waves' VALU work on this part -- scripts/probe/mfma_overlap_probe.hip: the two
-// add up -- so the contraction costs its ~40 cycles of SIMD time per instruction; that is still less than half of the
-// partial products + transposed butterfly it replaces, and it needs no cross-lane instruction.)  Basis rows i = 4 g + r are laid out so that the four
+// that own the pixels and multiplied by a constant 64 x 16 basis with sixteen v_mfma_f32_16x16x4_f32 (exact fp32):
+// D[i][j] = sum_p F[i][p] * data[j][p].  (An fp32 MFMA does not run beside other waves' VALU work on this part --
+// scripts/probe/mfma_overlap_probe.hip: the two add up -- so the contraction costs its ~40 cycles of SIMD time per
+// instruction; that is still less than half of the partial products + transposed butterfly it replaces.)
+// Basis rows i = 4 g + r are laid out so that the four
 // accumulator registers of a lane (g = lane >> 4, column j = lane & 15) hold everything ONE output needs:
 //   g = 0: 1, cx, cy, cx^2 -> conic.x, mean.x     g = 1: 1, cx, cy, cx cy -> conic.y, mean.y
 //   g = 2: 1, cx, cy, cy^2 -> conic.w, opacity    g = 3: dL_dpixel r, g, b -> colour (u columns only)
