@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         }
     }
     if (idx >= a.P) return;
+    __shared__ float4 xpose[4][256];   // per wave: 64 Splat lines on their way to coalesced stores
 
     const V3 p_orig = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     float cov6[6];
@@ -209,19 +210,43 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         a.radii[(size_t)vw * a.P + idx] = radius_out;
         at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
         at_view(a.dkey, a.g_stride, vw)[idx] = key;
-        Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
-        sp->q0 = s.q0;
-        sp->q1 = s.q1;
-        sp->q2 = s.q2;
         // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
         // Gaussian; the whole 64-B line is written here
-        sp->q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
+        const float4 q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
+        const int wave_first = idx - (int)(threadIdx.x & 63);
+        const bool full_wave = wave_first + 64 <= a.P;   // wave-uniform
+        if (full_wave) {
+            // The wave's 64 lines are 4 KB in a row.  A lane storing its own line issues four stores whose lanes are 64 B apart
+            // (64 requests of 16 B each); through the wave's LDS slice the same bytes leave as four stores of consecutive
+            // 16-B chunks (16 requests of 64 B each).  DS operations of a wave execute in order: no barrier.
+            float4* mine = xpose[threadIdx.x >> 6] + 4 * (threadIdx.x & 63);
+            mine[0] = s.q0; mine[1] = s.q1; mine[2] = s.q2; mine[3] = q3;
+            __builtin_amdgcn_wave_barrier();
+            const float4* rd = xpose[threadIdx.x >> 6] + (threadIdx.x & 63);
+            float4* out = reinterpret_cast<float4*>(at_view(a.splat, a.g_stride, vw) + wave_first) + (threadIdx.x & 63);
+            const float4 t0 = rd[0], t1 = rd[64], t2 = rd[128], t3 = rd[192];
+            out[0] = t0; out[64] = t1; out[128] = t2; out[192] = t3;
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
+            sp->q0 = s.q0;
+            sp->q1 = s.q1;
+            sp->q2 = s.q2;
+            sp->q3 = q3;
+        }
         if (a.need_backward) {
             at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
             // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
-            float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.gr_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
+            if (full_wave) {
+                // the wave's 64 records are 4 KB in a row: consecutive lanes on consecutive 16-B chunks (16 requests of 64 B
+                // per store instruction instead of 64 requests of 16 B)
+                float4* recw = reinterpret_cast<float4*>(at_view(a.grad_rec, a.gr_stride, vw) + (size_t)wave_first * GRAD_REC_WORDS) + (threadIdx.x & 63);
+                recw[0] = z; recw[64] = z; recw[128] = z; recw[192] = z;
+            } else {
+                float4* rec = reinterpret_cast<float4*>(at_view(a.grad_rec, a.gr_stride, vw) + (size_t)idx * GRAD_REC_WORDS);
+                rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
+            }
         }
     }
 }
