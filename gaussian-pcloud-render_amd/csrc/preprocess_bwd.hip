@@ -57,6 +57,7 @@ template <int DEG> constexpr int sh_words() { return 3 * (DEG + 1) * (DEG + 1); 
 struct PreBwdArgs {
     int P, D, M, V;
     int stage_sh;                        // dL_dsh rows go through LDS (256 x 3 M floats fit)
+    int stage_out;                       // the 3- and 6-float gradient rows go through LDS too
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
     const float *means3D, *shs, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
@@ -145,6 +146,34 @@ __device__ __forceinline__ V3 sh_backward(V3 pos, V3 campos, const float* sh, ui
 #undef SHV
     const V3 dL_ddir = v3(dot3(dRGBdx, dL_dRGB), dot3(dRGBdy, dL_dRGB), dot3(dRGBdz, dL_dRGB));
     return dnormvdv(dir_orig, dL_ddir);
+}
+
+// ---- 3D covariance -> scale, rotation (the sum over views entered gS linearly, so this runs once per Gaussian)
+__device__ __forceinline__ void scale_rot_backward(V3 sc, float4 q, float scale_modifier, const float (&gS)[6], float (&dsc)[3], float4& dq)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    // columns of the rotation (raw quaternion, as the forward builds it)
+    const V3 c0 = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y));
+    const V3 c1 = v3(2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x));
+    const V3 c2 = v3(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y));
+    const V3 s = v3(scale_modifier * sc.x, scale_modifier * sc.y, scale_modifier * sc.z);
+    const V3 a0 = s.x * c0, a1 = s.y * c1, a2 = s.z * c2;
+    // e_k = 2 G a_k with G the full symmetric matrix (off-diagonals of the 6-vector halved)
+    const float Gxx = gS[0], Gxy = 0.5f * gS[1], Gxz = 0.5f * gS[2], Gyy = gS[3], Gyz = 0.5f * gS[4], Gzz = gS[5];
+#define GMUL(v) v3(2.f * (Gxx * (v).x + Gxy * (v).y + Gxz * (v).z), 2.f * (Gxy * (v).x + Gyy * (v).y + Gyz * (v).z), \
+                   2.f * (Gxz * (v).x + Gyz * (v).y + Gzz * (v).z))
+    const V3 e0 = GMUL(a0), e1 = GMUL(a1), e2 = GMUL(a2);
+#undef GMUL
+    dsc[0] = dot3(c0, e0);
+    dsc[1] = dot3(c1, e1);
+    dsc[2] = dot3(c2, e2);
+    // Q_ij = dL/dR_ij: column k of Q is s_k e_k
+    const V3 Q0 = s.x * e0, Q1 = s.y * e1, Q2 = s.z * e2;
+    const float Q00 = Q0.x, Q10 = Q0.y, Q20 = Q0.z, Q01 = Q1.x, Q11 = Q1.y, Q21 = Q1.z, Q02 = Q2.x, Q12 = Q2.y, Q22 = Q2.z;
+    dq.x = 2 * z * (Q10 - Q01) + 2 * y * (Q02 - Q20) + 2 * x * (Q21 - Q12);
+    dq.y = 2 * y * (Q01 + Q10) + 2 * z * (Q02 + Q20) + 2 * r * (Q21 - Q12) - 4 * x * (Q11 + Q22);
+    dq.z = 2 * x * (Q01 + Q10) + 2 * r * (Q02 - Q20) + 2 * z * (Q12 + Q21) - 4 * y * (Q00 + Q22);
+    dq.w = 2 * r * (Q10 - Q01) + 2 * x * (Q02 + Q20) + 2 * y * (Q12 + Q21) - 4 * z * (Q00 + Q11);
 }
 
 // DEG = active SH degree (a template parameter so that the per-view SH sums take 3 (DEG+1)^2 registers, not 48)
@@ -288,6 +317,44 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
             for (int i = NSH; i < W3; i++) out[i] = 0.f;
         }
     }
+    // The 3- and 6-float rows (mean2D, colour, mean3D, 3D covariance, scale) leave through the staging area too: a lane storing
+    // its own row issues scalar stores 12 or 24 B apart (12-24 partial-line requests per instruction); staged, the workgroup
+    // writes each array's 256 rows as one run of 16-B chunks.
+    float dsc[3] = {0.f, 0.f, 0.f};
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scales) scale_rot_backward(sc, q, a.scale_modifier, gS, dsc, dq);
+    if (a.stage_out) {
+        __syncthreads();   // the dL_dsh rows have left the staging area
+        float* o = s_rows;
+        const uint32_t t = threadIdx.x;
+        o[3 * t + 0] = g2x; o[3 * t + 1] = g2y; o[3 * t + 2] = 0.f;
+        o += 768;
+        o[3 * t + 0] = gcol.x; o[3 * t + 1] = gcol.y; o[3 * t + 2] = gcol.z;
+        o += 768;
+        o[3 * t + 0] = gmean.x; o[3 * t + 1] = gmean.y; o[3 * t + 2] = gmean.z;
+        o += 768;
+        o[3 * t + 0] = dsc[0]; o[3 * t + 1] = dsc[1]; o[3 * t + 2] = dsc[2];
+        o += 768;
+#pragma unroll
+        for (int i = 0; i < 6; i++) o[6 * t + i] = gS[i];
+        __syncthreads();
+        const int rows = a.P - (int)blockIdx.x * 256 < 256 ? a.P - (int)blockIdx.x * 256 : 256;
+        float* const dst[5] = {a.dL_dmean2D, a.dL_dcolor, a.dL_dmean3D, a.scales ? a.dL_dscale : nullptr, a.dL_dcov3D};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int wdt = k == 4 ? 6 : 3, total = rows * wdt;
+            const float* src = s_rows + 768 * k;
+            if (dst[k] == nullptr) continue;
+            float* out = dst[k] + (size_t)blockIdx.x * 256 * wdt;   // 256 rows of 12 or 24 B per block: 16-B aligned
+            for (int j = 4 * (int)t; j + 3 < total; j += 4 * 256)
+                *reinterpret_cast<float4*>(out + j) = *reinterpret_cast<const float4*>(src + j);
+            if ((int)t < (total & 3)) out[(total & ~3) + t] = src[(total & ~3) + t];
+        }
+        if (!active) return;
+        a.dL_dopacity[idx] = gop;
+        if (a.scales) *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
+        return;
+    }
     if (!active) return;
     a.dL_dmean2D[3 * (size_t)idx + 0] = g2x;
     a.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
@@ -302,32 +369,10 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
 #pragma unroll
     for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = gS[i];
 
-    // ---- 3D covariance -> scale, rotation (the sum over views entered gS linearly, so this runs once)
     if (a.scales) {
-        const float r = q.x, x = q.y, y = q.z, z = q.w;
-        // columns of the rotation (raw quaternion, as the forward builds it)
-        const V3 c0 = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y));
-        const V3 c1 = v3(2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x));
-        const V3 c2 = v3(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y));
-        const V3 s = v3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
-        const V3 a0 = s.x * c0, a1 = s.y * c1, a2 = s.z * c2;
-        // e_k = 2 G a_k with G the full symmetric matrix (off-diagonals of the 6-vector halved)
-        const float Gxx = gS[0], Gxy = 0.5f * gS[1], Gxz = 0.5f * gS[2], Gyy = gS[3], Gyz = 0.5f * gS[4], Gzz = gS[5];
-#define GMUL(v) v3(2.f * (Gxx * (v).x + Gxy * (v).y + Gxz * (v).z), 2.f * (Gxy * (v).x + Gyy * (v).y + Gyz * (v).z), \
-                   2.f * (Gxz * (v).x + Gyz * (v).y + Gzz * (v).z))
-        const V3 e0 = GMUL(a0), e1 = GMUL(a1), e2 = GMUL(a2);
-#undef GMUL
-        a.dL_dscale[3 * (size_t)idx + 0] = dot3(c0, e0);
-        a.dL_dscale[3 * (size_t)idx + 1] = dot3(c1, e1);
-        a.dL_dscale[3 * (size_t)idx + 2] = dot3(c2, e2);
-        // Q_ij = dL/dR_ij: column k of Q is s_k e_k
-        const V3 Q0 = s.x * e0, Q1 = s.y * e1, Q2 = s.z * e2;
-        const float Q00 = Q0.x, Q10 = Q0.y, Q20 = Q0.z, Q01 = Q1.x, Q11 = Q1.y, Q21 = Q1.z, Q02 = Q2.x, Q12 = Q2.y, Q22 = Q2.z;
-        float4 dq;
-        dq.x = 2 * z * (Q10 - Q01) + 2 * y * (Q02 - Q20) + 2 * x * (Q21 - Q12);
-        dq.y = 2 * y * (Q01 + Q10) + 2 * z * (Q02 + Q20) + 2 * r * (Q21 - Q12) - 4 * x * (Q11 + Q22);
-        dq.z = 2 * x * (Q01 + Q10) + 2 * r * (Q02 - Q20) + 2 * z * (Q12 + Q21) - 4 * y * (Q00 + Q22);
-        dq.w = 2 * r * (Q10 - Q01) + 2 * x * (Q02 + Q20) + 2 * y * (Q12 + Q21) - 4 * z * (Q00 + Q11);
+        a.dL_dscale[3 * (size_t)idx + 0] = dsc[0];
+        a.dL_dscale[3 * (size_t)idx + 1] = dsc[1];
+        a.dL_dscale[3 * (size_t)idx + 2] = dsc[2];
         *reinterpret_cast<float4*>(a.dL_drot + 4 * (size_t)idx) = dq;
     }
 }
@@ -352,6 +397,9 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch
     size_t lds = p.shs ? (size_t)256 * 3 * p.M * sizeof(float) : 0;
     a.stage_sh = lds != 0 && lds <= 64 * 1024;
     if (!a.stage_sh) lds = 0;
+    const size_t lds_out = (size_t)(4 * 768 + 6 * 256) * sizeof(float);   // the staged 3- and 6-float rows of a workgroup
+    a.stage_out = true;
+    if (lds < lds_out) lds = lds_out;
     switch (p.shs ? p.D : 0) {
     case 0: hipLaunchKernelGGL(k_preprocess_backward<0>, grid, block, lds, L.stream, a); break;
     case 1: hipLaunchKernelGGL(k_preprocess_backward<1>, grid, block, lds, L.stream, a); break;
