@@ -260,33 +260,43 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     // the emission kernel leaves the counters of every view in mapped host memory; the event behind it is waited for only
     // after the rest of the frame has been enqueued
     memset(t_land.pinned, 0, (size_t)V * 4 * sizeof(uint64_t));
-    {
-        ProfScope ps("duplicate", L.stream);
-        if (int e = launch_duplicate(L, p->P, B, gridx, key16, t_land.mapped)) return e;
-    }
-    {
-        g_d2h_count++;
-        const hipError_t e = hipEventRecord(t_land.ev, L.stream);
-        if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
-    }
-    if (mode != 2) {
-        const int res = sorted_buffer(T);
+    // Once the emission is in the stream it WILL store into the landing zone, whatever happens to the launches behind it: an
+    // early return must not leave it pending (the next call of this thread clears the zone from the host and would race
+    // with those late stores), so every error path below drains the stream first.
+    const auto rest = [&]() -> int {
         {
-            ProfScope ps("tile_sort", L.stream);
-            SortJob job{{B.b.key[0], B.b.key[1]}, {B.b.val[0], B.b.val[1]}, B.b.hist, B.b.totals, B.b_stride,
-                        B.g.counters + CNT_NUM_RENDERED, B.g_stride, B.b.cap, V};
-            int r2 = 0;
-            if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
+            ProfScope ps("duplicate", L.stream);
+            if (int e = launch_duplicate(L, p->P, B, gridx, key16, t_land.mapped)) return e;
         }
         {
-            ProfScope ps("tile_ranges", L.stream);
-            if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
-            if (int e = launch_tile_order(L, B, T)) return e;
+            g_d2h_count++;
+            const hipError_t e = hipEventRecord(t_land.ev, L.stream);
+            if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back: %s", hipGetErrorString(e));
         }
-        {
-            ProfScope ps("render_forward", L.stream);
-            if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0, X)) return e;
+        if (mode != 2) {
+            const int res = sorted_buffer(T);
+            {
+                ProfScope ps("tile_sort", L.stream);
+                SortJob job{{B.b.key[0], B.b.key[1]}, {B.b.val[0], B.b.val[1]}, B.b.hist, B.b.totals, B.b_stride,
+                            B.g.counters + CNT_NUM_RENDERED, B.g_stride, B.b.cap, V};
+                int r2 = 0;
+                if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
+            }
+            {
+                ProfScope ps("tile_ranges", L.stream);
+                if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
+                if (int e = launch_tile_order(L, B, T)) return e;
+            }
+            {
+                ProfScope ps("render_forward", L.stream);
+                if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0, X)) return e;
+            }
         }
+        return GSR_OK;
+    };
+    if (int e = rest()) {
+        (void)hipStreamSynchronize(L.stream);   // (keeps g_err: the failure being reported)
+        return e;
     }
     if (hipEventSynchronize(t_land.ev) != hipSuccess)
         return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
@@ -404,6 +414,7 @@ int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void*
         return fail(GSR_ERR_INVALID, "[gsr] a required backward pointer is NULL");
     if (p->shs && !dL_dsh) return fail(GSR_ERR_INVALID, "[gsr] dL_dsh is NULL");
     if (p->scales && (!dL_dscale || !dL_drot)) return fail(GSR_ERR_INVALID, "[gsr] dL_dscale/dL_drot is NULL");
+    if (p->scales && ((uintptr_t)dL_drot & 15u)) return fail(GSR_ERR_INVALID, "[gsr] dL_drot must be 16-byte aligned (it is written one float4 per Gaussian)");
     if (!binning) return fail(GSR_ERR_INVALID, "[gsr] binning arena is NULL");
     Batch B;
     if (int e = make_batch(p, V, const_cast<void*>(geom), geom_bytes, const_cast<void*>(image), image_bytes,

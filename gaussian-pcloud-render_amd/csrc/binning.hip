@@ -435,7 +435,7 @@ int launch_tile_order(const Launch& L, const Batch& B, int T)
 // whole list.  Items are emitted heaviest first with the same bucket scheme as tile_order; a tile's chunk number
 // BWD_MAX_CHUNKS-1 takes everything that is left.  item = tile | chunk << BWD_TILE_BITS.
 // Workgroups with blockIdx.y > 0 are the guard against a REPEATED backward over one forward: when the view's gradient
-// records were already consumed by a backward (CNT_BWD_DIRTY, raised by k_preprocess_backward) they clear them before the
+// records were already consumed by a backward (CNT_BWD_DIRTY, raised by k_render_backward as it starts) they clear them before the
 // render backward accumulates again; normally they read one word and leave.
 constexpr int BWD_CLEAR_BLOCKS = 64;
 __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,

@@ -65,7 +65,7 @@ struct PreBwdArgs {
     const uint8_t* clamped;
     const float* grad_rec;               // [P][GRAD_REC_WORDS] per view, see common.hpp
     size_t g_stride, gr_stride;
-    uint64_t* counters;                  // per view (CNT_*): CNT_BWD_DIRTY is raised once the records have been consumed
+    uint64_t* counters;                  // per view (CNT_*)
     float *dL_dmean2D, *dL_dopacity, *dL_dcolor;
     float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
@@ -184,10 +184,9 @@ __global__ __launch_bounds__(256) void k_preprocess_backward(PreBwdArgs a)
     const bool active = blockIdx.x * 256 + threadIdx.x < (unsigned)a.P;
     const int idx = active ? (int)(blockIdx.x * 256 + threadIdx.x) : a.P - 1;   // idle lanes of the last block shadow a real one
 
-    // The records now hold this backward's sums.  A further backward over the same forward (retain_graph, a second
-    // gsr_backward call) must not add to them: it finds the flag and clears the records first (k_bwd_items), where the
-    // reference zero-fills its accumulators on every call (rasterize_points.cu:151-159).
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)a.V) at_view(a.counters, a.g_stride, threadIdx.x)[CNT_BWD_DIRTY] = 1;
+    // (The records hold this backward's sums; k_render_backward raised CNT_BWD_DIRTY so that a further backward over the same
+    // forward -- retain_graph, a second gsr_backward call -- clears them first (k_bwd_items), where the reference zero-fills
+    // its accumulators on every call, rasterize_points.cu:151-159.)
 
     // sums over the views of the batch
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
@@ -395,11 +394,15 @@ int launch_preprocess_backward(const Launch& L, const gsr_params& p, const Batch
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
     const dim3 grid((p.P + 255) / 256), block(256);
     size_t lds = p.shs ? (size_t)256 * 3 * p.M * sizeof(float) : 0;
-    a.stage_sh = lds != 0 && lds <= 64 * 1024;
+    // the staged paths write 16-B chunks from each array's base (+ a multiple of 16 B per workgroup): they need 16-B aligned
+    // output pointers (include/gsr.h asks for that; every torch / hipMalloc allocation is).  A caller that hands over a
+    // float-aligned sub-buffer gets the per-row scalar stores instead.
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15u) == 0; };
+    a.stage_sh = lds != 0 && lds <= 64 * 1024 && al16(dL_dsh);
     if (!a.stage_sh) lds = 0;
     const size_t lds_out = (size_t)(4 * 768 + 6 * 256) * sizeof(float);   // the staged 3- and 6-float rows of a workgroup
-    a.stage_out = true;
-    if (lds < lds_out) lds = lds_out;
+    a.stage_out = al16(dL_dmean2D) && al16(dL_dcolor) && al16(dL_dmean3D) && al16(dL_dcov3D) && (!p.scales || al16(dL_dscale));
+    if (a.stage_out && lds < lds_out) lds = lds_out;
     switch (p.shs ? p.D : 0) {
     case 0: hipLaunchKernelGGL(k_preprocess_backward<0>, grid, block, lds, L.stream, a); break;
     case 1: hipLaunchKernelGGL(k_preprocess_backward<1>, grid, block, lds, L.stream, a); break;

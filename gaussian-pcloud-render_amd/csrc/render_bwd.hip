@@ -30,6 +30,13 @@ namespace gsr {
 
 constexpr int BGRP = 4;  // entries evaluated per inner-loop trip
 
+#ifndef GSR_BWD_DIV
+#define GSR_BWD_DIV 1   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
+#endif
+#ifndef GSR_BWD_NOFMA
+#define GSR_BWD_NOFMA 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // see render_fwd.hip: prefetch loads hidden from hipcc's waitcnt pass, retired by hand
@@ -155,6 +162,39 @@ __device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am
     return acc;
 }
 
+#ifdef GSR_BWD_EMUL
+// DIAGNOSTIC build only (scripts/gpu_session_r4b.sh): the same contraction as mm_contract by plain arithmetic, pixels in
+// raster order -- GSR_BWD_EMUL = 1: float fmaf chain, 2: double -- to tell the matrix cores' summation apart from the
+// moment shift when the accuracy of the sums is in question.  dpx: [3][64] dL_dpixel of the item, raster order.
+__device__ __forceinline__ f32x4 mm_contract_emul(const float* mrow, const float* dpx, uint32_t lane)
+{
+    const uint32_t j = lane & 15u;
+    f32x4 acc;
+    for (int r = 0; r < 4; r++) {
+        const uint32_t i = 4u * (lane >> 4) + (uint32_t)r;
+#if GSR_BWD_EMUL == 2
+        double sum = 0.0;
+#else
+        float sum = 0.f;
+#endif
+        for (uint32_t p = 0; p < 64u; p++) {
+            const float cx = (float)(p & 7u) - 3.5f, cy = (float)(p >> 3) - 3.5f;
+            const uint32_t c = i & 3u;
+            float f = c == 0 ? 1.f : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
+            if (i >= 12u) f = i < 15u ? dpx[(i - 12u) * 64u + p] : 0.f;
+            const float d = mrow[j * MM_STRIDE + mm_pos(p)];
+#if GSR_BWD_EMUL == 2
+            sum += (double)f * (double)d;
+#else
+            sum = __builtin_fmaf(f, d, sum);
+#endif
+        }
+        acc[r] = (float)sum;
+    }
+    return acc;
+}
+#endif
+
 __global__ void k_selftest_mm(float* out256)
 {
     __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];
@@ -251,6 +291,7 @@ struct RenderBwdArgs {
     const uint32_t* n_contrib;
     const float* dL_dpix;
     float* grad_rec;     // [P][GRAD_REC_WORDS] accumulation records (common.hpp)
+    uint64_t* counters;  // per view (CNT_*)
     uint32_t V;
     size_t g_stride, b_stride, iv_stride, gr_stride;
 };
@@ -277,9 +318,16 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     a.grad_rec = at_view(a.grad_rec, a.gr_stride, view);
     a.dL_dpix += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     const uint32_t n_items = at_view(a.item_count, a.iv_stride, view)[0];
+    // From here on this view's gradient records hold sums of THIS backward: a later backward on the same arenas has to clear
+    // them first (k_bwd_items reads the flag; it has finished: stream order).  Raised before anything is accumulated, so a
+    // backward that fails half-way still leaves the records marked.
+    if (group < a.V && (blockIdx.x & 31u) == 0 && threadIdx.x == 0) at_view(a.counters, a.g_stride, view)[CNT_BWD_DIRTY] = 1;
     // group 16 keeps the entries of a batch that is still open when its round ends (the next round restages groups 0..15)
     __shared__ __attribute__((aligned(16))) float stage[17 * QUAD_WORDS];
     __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];   // 8 entries x {q, u} rows x 64 pixels
+#ifdef GSR_BWD_EMUL
+    __shared__ float dpx_raster[3 * 64];
+#endif
     float am[16];                                                          // A operands of the 16 K steps (basis)
     mm_basis(am, threadIdx.x);
     const uint32_t mm_p = mm_pos(threadIdx.x);                              // this lane's pixel in a row
@@ -348,6 +396,9 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     bg_dot_dpixel += a.bg[2] * dpx2;
     mrow[mm_p] = dpx0; mrow[MM_STRIDE + mm_p] = dpx1; mrow[2 * MM_STRIDE + mm_p] = dpx2;
     mm_basis_dpx(am, mrow, lane);
+#ifdef GSR_BWD_EMUL
+    dpx_raster[lane] = dpx0; dpx_raster[64 + lane] = dpx1; dpx_raster[128 + lane] = dpx2;
+#endif
     const float mm_sx = x0f + 3.5f, mm_sy = y0f + 3.5f;   // quadrant centre
 
     // Where this lane's reduced value goes.  Even lane 2i owns value i of the 32-batch: entry k = i >> 3 of the group,
@@ -514,12 +565,38 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             for (int k = 0; k < BGRP; k++) {
                 const bool hit = hits[k];
                 const float alpha = hit ? alphas[k] : 0.f;
-                const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float om = 1.f - alpha;
+#if GSR_BWD_DIV == 0
+                const float rcp = __builtin_amdgcn_rcpf(om);
                 const float Tn = T * rcp;
+#elif GSR_BWD_DIV == 1
+                // T / (1 - alpha) as the reference writes it (CR/backward.cu:503), without the ten instructions of the generic
+                // division: v_rcp_f32 (1 ulp) gives the quotient to ~1.5 ulp, one residual step T - om * q (exact in the FMA)
+                // brings it to the correctly rounded value except when the exact quotient lies within ~2^-22 ulp of a rounding
+                // boundary.  No scaling is needed: om is in [0.01, 1] and T in [1e-4 * 0.01, 1].
+                const float rcp = __builtin_amdgcn_rcpf(om);
+                const float q0 = T * rcp;
+                const float Tn = __builtin_fmaf(__builtin_fmaf(-om, q0, T), rcp, q0);
+#elif GSR_BWD_DIV == 2
+                const float r0 = __builtin_amdgcn_rcpf(om);
+                const float rcp = __builtin_fmaf(__builtin_fmaf(-om, r0, 1.f), r0, r0);
+                const float q0 = T * rcp;
+                const float Tn = __builtin_fmaf(__builtin_fmaf(-om, q0, T), rcp, q0);
+#else
+                const float rcp = 1.f / om;
+                const float Tn = T / om;
+#endif
+#if GSR_BWD_NOFMA
+                const float d = (er[k] * dpx0 + eg[k] * dpx1) + eb[k] * dpx2;
+                const float sn = last_alpha * last_d + (1.f - last_alpha) * s_rec;
+                float dL_dalpha = (d - sn) * Tn;
+                dL_dalpha = dL_dalpha + (-T_final * rcp) * bg_dot_dpixel;
+#else
                 const float d = __builtin_fmaf(eb[k], dpx2, __builtin_fmaf(eg[k], dpx1, er[k] * dpx0));
                 const float sn = __builtin_fmaf(last_alpha, last_d - s_rec, s_rec);  // la*last_d + (1-la)*s
                 float dL_dalpha = (d - sn) * Tn;
                 dL_dalpha = __builtin_fmaf(-T_final * rcp, bg_dot_dpixel, dL_dalpha);
+#endif
                 // lanes that do not hit contribute exact zeros: every product of phase 2 carries a factor Gh or alpha*T
                 // (dL_dalpha itself stays finite, so 0 * dL_dalpha is 0)
                 dLa[k] = dL_dalpha;
@@ -561,9 +638,21 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
             // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
+#ifdef GSR_BWD_EMUL
+            const f32x4 acc = mm_contract_emul(mrow, dpx_raster, lane);
+#else
             const f32x4 acc = mm_contract(mrow, am, lane, hit_blocks);
-            const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
+#endif
             const float S1 = acc.x, Sx = acc.y, Sy = acc.z, V3 = acc.w;
+#ifdef GSR_BWD_SHIFT64
+            // DIAGNOSTIC: the moment shift in double
+            const double bxd = (double)eX - (double)mm_sx, byd = (double)eY - (double)mm_sy;
+            const double Dxd = bxd * S1 - Sx, Dyd = byd * S1 - Sy;
+            const double t2d = (mm_g == 0 ? bxd : byd) * (mm_g == 2u ? Dyd : Dxd) - (mm_g == 2u ? byd : bxd) * (mm_g == 0 ? Sx : Sy) + V3;
+            float o1 = (float)(-0.5 * cO * t2d);
+            float o2 = (float)(((double)cO * mm_dd) * ((double)cP * Dxd + (double)cQ * Dyd));
+#else
+            const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
             const float Dx = __builtin_fmaf(bx, S1, -Sx), Dy = __builtin_fmaf(by, S1, -Sy);   // sum q dx, sum q dy
             // second moments about the splat centre: sum q dx^2 = bx Dx - bx Sx + Sxx, sum q dx dy = by Dx - bx Sy + Sxy,
             // sum q dy^2 = by Dy - by Sy + Syy
@@ -571,6 +660,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                                             __builtin_fmaf(-(mm_g == 2u ? by : bx), mm_g == 0 ? Sx : Sy, V3));
             float o1 = -0.5f * cO * t2;                                                  // conic x | y | w
             float o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                   // mean2D x | y
+#endif
             if (mm_g == 2u) o2 = S1;                                                     // opacity
             if (mm_u) { o1 = acc.x; o2 = acc.y; }                                        // colour r, g (row 3, u columns)
             const float o3 = acc.z;                                                      // colour b
@@ -645,6 +735,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     a.n_contrib = B.iv.n_contrib;
     a.dL_dpix = dL_dpix;
     a.grad_rec = B.grad_rec; a.gr_stride = B.gr_stride;
+    a.counters = B.g.counters;
     a.num_tiles = a.gridx * gridy;
     a.V = (uint32_t)B.V;
     a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;

@@ -64,7 +64,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         )
         need_backward = any(ctx.needs_input_grad)
         if rs.debug:
-            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            cpu_args = cpu_deep_copy_tuple(args)
             try:
                 num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
                     *args, need_backward=need_backward)
@@ -150,7 +150,6 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def markVisible(self, positions):
-        # Mark visible points (based on frustum culling for camera) with a boolean
         with torch.no_grad():
             raster_settings = self.raster_settings
             visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
@@ -200,19 +199,47 @@ class GaussianRasterizer(nn.Module):
 # a training loop hands over the same settings objects every iteration, and rebuilding the blocks (36 tiny copies + 3 stacks)
 # or comparing backgrounds through host memory (a blocking device->host copy per view, which drains the stream) would put
 # the host back on the critical path of every call.  Steady state: no torch kernel, no copy, no synchronisation.
+#
+# What the cache can and cannot see.  A tensor is identified by (address, shape, strides, version counter, device): in-place
+# edits through torch (`m.copy_(..)`, `m[0, 0] = ..`, `m.mul_(..)`) bump the version counter and repack the blocks.  Writes
+# that bypass the counter -- `m.data.copy_(..)`, a numpy array sharing a CPU tensor's memory -- are invisible to it and would
+# render with the packed (stale) matrices: build new tensors for new cameras, or switch the cache off
+# (GSR_VIEW_CACHE=0 in the environment, or diff_gaussian_rasterization.set_view_cache(False)): the blocks are then packed
+# on every call, as the reference's caller does.  Tensors created under torch.inference_mode() carry no version counter: a
+# settings list that contains one is never cached.
+import os as _os
+
 _VIEW_BLOCKS = {}          # key -> (view, proj, cam, the source tensors kept alive so that their addresses cannot be reused)
 _VIEW_BLOCKS_MAX = 32
-_BG_SAME = {}              # (ptr, version, ptr, version) -> the two background tensors hold the same three values
+_BG_SAME = {}              # (key of a, key of b) -> the two background tensors hold the same three values
+_VIEW_CACHE_ON = _os.environ.get("GSR_VIEW_CACHE", "1") != "0"
+
+
+def set_view_cache(on):
+    """Switch the packed-view-block cache of rasterize_views on or off (off: pack the per-view matrices on every call)."""
+    global _VIEW_CACHE_ON
+    _VIEW_CACHE_ON = bool(on)
+    if not on:
+        _VIEW_BLOCKS.clear()
+        _BG_SAME.clear()
 
 
 def _tkey(t):
-    return (t.data_ptr(), t._version, t.device.type, t.device.index)
+    """Identity of a tensor's current contents as far as torch tracks it, or None when it does not (inference tensors)."""
+    try:
+        ver = t._version
+    except RuntimeError:
+        return None
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), ver, t.device.type, t.device.index)
 
 
 def _same_background(a, b):
-    if a is b or (a.data_ptr() == b.data_ptr() and a.device == b.device and a.numel() == b.numel()):
+    if a is b or (a.data_ptr() == b.data_ptr() and a.device == b.device and a.shape == b.shape and a.stride() == b.stride()):
         return True
-    k = _tkey(a) + _tkey(b)
+    ka, kb = _tkey(a), _tkey(b)
+    if not _VIEW_CACHE_ON or ka is None or kb is None:
+        return torch.equal(a.detach().cpu(), b.detach().cpu())
+    k = ka + kb
     r = _BG_SAME.get(k)
     if r is None:
         if len(_BG_SAME) >= 256:
@@ -220,6 +247,13 @@ def _same_background(a, b):
         r = (torch.equal(a.detach().cpu(), b.detach().cpu()), a, b)     # one host comparison per pair of tensors, ever
         _BG_SAME[k] = r
     return r[0]
+
+
+def _pack_views(settings_list, device):
+    view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+    proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
+    cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
+    return view, proj, cam
 
 
 def _stack_views(settings_list, device):
@@ -231,14 +265,14 @@ def _stack_views(settings_list, device):
             raise Exception("rasterize_views: the views of a batch must share image size, tan(fov), background, scale "
                             "modifier, SH degree and the prefiltered flag")
     _C._require_hip(device)
-    key = (device.type, device.index) + tuple(k for s in settings_list for t in (s.viewmatrix, s.projmatrix, s.campos)
-                                               for k in _tkey(t))
+    keys = [_tkey(t) for s in settings_list for t in (s.viewmatrix, s.projmatrix, s.campos)]
+    if not _VIEW_CACHE_ON or any(k is None for k in keys):
+        return _pack_views(settings_list, device)
+    key = (device.type, device.index) + tuple(keys)
     hit = _VIEW_BLOCKS.get(key)
     cur = torch.cuda.current_stream(device)
     if hit is None:
-        view = torch.stack([s.viewmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
-        proj = torch.stack([s.projmatrix.reshape(4, 4).to(device) for s in settings_list], 0).contiguous()
-        cam = torch.stack([s.campos.reshape(3).to(device) for s in settings_list], 0).contiguous()
+        view, proj, cam = _pack_views(settings_list, device)
         # other host threads may pick the blocks up on other streams: they wait (on the device) for this event, nobody waits
         # on the host
         ev = torch.cuda.Event()

@@ -296,10 +296,11 @@ def recolor(background, means3D, colors, sh, degree, campos, image_height, image
 
 def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                        viewmatrices, projmatrices, tan_fovx, tan_fovy, dL_dout_color, sh, degree, camposs,
-                                       geomBuffer, binningBuffer, imageBuffer, debug):
+                                       geomBuffer, binningBuffer, imageBuffer, debug, _alloc=None):
     """Backward of rasterize_gaussians_batch: dL_dout_color [V,3,H,W], radii [V,P]; gradients summed over the views.
     Returns the reference's 8-tuple (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
-    dL_drotations)."""
+    dL_drotations).  _alloc(shape, dtype=, device=): allocator of the outputs (tests hand over float-aligned views to
+    exercise the C ABI's alignment fallback; default torch.empty)."""
     device = means3D.device
     _require_hip(device)
     P = means3D.shape[0]
@@ -309,7 +310,7 @@ def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scale
     # Nothing is cleared here: the per-Gaussian backward kernel writes every output for every Gaussian (the reference
     # zero-fills nine tensors, rasterize_points.cu:151-159), and the accumulation records live in the geometry arena.
     has_sr = scales.numel() != 0 and P != 0
-    e_or_z = torch.empty if P != 0 else torch.zeros
+    e_or_z = (_alloc or torch.empty) if P != 0 else torch.zeros
     dL_dmeans2D = e_or_z((P, 3), **z)
     dL_dcolors = e_or_z((P, 3), **z)
     dL_dopacity = e_or_z((P, 1), **z)
@@ -396,6 +397,21 @@ def query(name, P, W, H, R, geom, binning, img, view=0, n_views=1):
                              img.data_ptr() + view * i_stride, int(R), out.data_ptr(), out.numel() * out.element_size(),
                              torch.cuda.current_stream(geom.device).cuda_stream))
     return out
+
+
+def grad_records(geom, P, view=0, n_views=1):
+    """The [P, 16] render-level gradient records of `view` (mean2D.xy, conic.xyw, colour rgb, opacity, 7 unused words) as the
+    last backward on these arenas left them: the counterpart of the reference's internal dL_dconic / dL_dmean2D / dL_dcolors /
+    dL_dopacity accumulators (rasterize_points.cu:151-159), for tests that pin the render backward on its own.  The records
+    follow the n_views per-view geometry arenas inside a need_backward geometry allocation (include/gsr.h)."""
+    g_stride = lib.gsr_geom_bytes_inference(P) - 256
+    gr_stride = lib.gsr_geom_bytes(P) - lib.gsr_geom_bytes_inference(P)
+    if geom.data_ptr() % 256:
+        raise RuntimeError("grad_records: arena base pointers are expected to be 256-byte aligned")
+    if geom.numel() < n_views * (g_stride + gr_stride):
+        raise RuntimeError("grad_records: not a need_backward geometry arena of %d views" % n_views)
+    off = n_views * g_stride + view * gr_stride
+    return geom[off:off + P * 64].view(torch.float32).view(P, 16).clone()
 
 
 def selftest(device):

@@ -68,14 +68,24 @@ def uv_lookup(texture, uv):
     return ((tex[ya, xa] * (1 - fx) + tex[ya, xb] * fx) * (1 - fy) + (tex[yb, xa] * (1 - fx) + tex[yb, xb] * fx) * fy)
 
 
-def read_obj(path, load_textures=True):
+def read_obj(path, load_textures=True, material_numbering="open3d"):
     """Wavefront OBJ reader: 'v x y z [r g b]', 'vt', 'vn', 'f' with v, v/vt, v//vn, v/vt/vn (polygons are fanned), 'mtllib',
     'usemtl'.  Returns dict(vertices [V,3] f64, faces [F,3] i64, colors [V,3] f64 or None, normals [V,3] f64 or None,
     triangle_uvs [F,3,2] f64 or None, material_ids [F] i64, textures: list of [h,w,3] float32 images in material order (open3d's
-    mesh.textures; only materials with a map_Kd), or [] )."""
+    mesh.textures; only materials with a map_Kd), or [] ).
+
+    material_numbering="open3d" (default, what the reference sees): material_ids index ALL materials of the MTL file(s) in file
+    order (open3d stores tinyobjloader's material index in triangle_material_ids; -1 for a `usemtl` the MTL does not define),
+    while `textures` holds only the materials with a map_Kd.  The reference pairs texture t with the triangles whose
+    material id == t (plib/render.py:158-173), so a textured material that FOLLOWS an untextured one in the MTL comes out black
+    and its texture lands on the wrong triangles -- a quirk of the reference that a drop-in reproduces; single-material scans
+    (THuman) and MTLs whose textured materials come first are unaffected.  material_numbering="textured" numbers only the
+    materials that carry a map_Kd, i.e. material id == index into `textures` (every textured triangle gets its own texture)."""
+    if material_numbering not in ("open3d", "textured"):
+        raise ValueError("material_numbering: 'open3d' or 'textured'")
     import os
     vs, cols, vns, vts, faces, face_n, face_t, face_m = [], [], [], [], [], [], [], []
-    mtl, mat_order, cur_mat = {}, [], None
+    mtl, mat_order, cur_mat = {}, [], None    # mat_order: the materials the MTL file(s) define, in file order
     with open(path, "r", errors="replace") as f:
         for line in f:
             p = line.split()
@@ -98,8 +108,6 @@ def read_obj(path, load_textures=True):
                             mat_order.append(k)
             elif p[0] == "usemtl":
                 cur_mat = " ".join(p[1:])
-                if cur_mat not in mat_order:
-                    mat_order.append(cur_mat)
             elif p[0] == "f":
                 idx, nidx, tidx = [], [], []
                 for tok in p[1:]:
@@ -128,9 +136,9 @@ def read_obj(path, load_textures=True):
     tri_uv = None
     if vts and len(face_t) == len(faces):
         tri_uv = np.asarray(vts, np.float64)[np.asarray(face_t, np.int64)]       # [F, 3, 2]
-    # open3d numbers the materials that carry a diffuse map in file order; triangle_material_ids index mesh.textures
-    tex_mats = [m for m in mat_order if mtl.get(m)]
-    mat_ids = np.asarray([tex_mats.index(m) if m in tex_mats else -1 for m in face_m], np.int64)
+    tex_mats = [m for m in mat_order if mtl.get(m)]          # open3d's mesh.textures: the materials with a diffuse map, file order
+    numbered = mat_order if material_numbering == "open3d" else tex_mats
+    mat_ids = np.asarray([numbered.index(m) if m in numbered else -1 for m in face_m], np.int64)
     textures = [load_texture(mtl[m]) for m in tex_mats] if (load_textures and tri_uv is not None) else []
     return dict(vertices=v, faces=fa, colors=np.asarray(cols, np.float64) if len(cols) == len(vs) and cols else None,
                 normals=normals, triangle_uvs=tri_uv, material_ids=mat_ids, textures=textures)

@@ -151,7 +151,10 @@ int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* g
  * lives in the geometry arena.  Valid after a forward with need_backward = 1 on the same arenas, any number of times: every
  * call returns the gradients of ITS dL_dpix (a repeated call first clears what the previous one accumulated).
  * shapes: radii[V,P] dL_dmean2D[P,3] dL_dopacity[P,1] dL_dcolor[P,3] dL_dmean3D[P,3] dL_dcov3D[P,6] dL_dsh[P,M,3]
- * dL_dscale[P,3] dL_drot[P,4]. */
+ * dL_dscale[P,3] dL_drot[P,4].
+ * Alignment: dL_drot must be 16-byte aligned (GSR_ERR_INVALID otherwise); the other gradient outputs should be -- every
+ * hipMalloc / torch allocation is -- because their rows then leave the kernel as whole 16-byte chunks; an output that is only
+ * float-aligned is still written correctly, through slower per-row stores. */
 int gsr_backward_batch(const gsr_params* p, int V, const int* radii, const void* geom, size_t geom_bytes, const void* binning,
                        size_t binning_bytes, const void* image, size_t image_bytes, const float* dL_dpix, float* dL_dmean2D,
                        float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,

@@ -304,16 +304,23 @@ static void inclusive_scan_u32_mt(int64_t n, const uint32_t *in, uint32_t *out, 
     const int64_t chunk = (n + nthreads - 1) / nthreads;
 #pragma omp parallel num_threads(nthreads)
     {
-        const int t = omp_get_thread_num();
-        const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
-        uint32_t acc = 0;
-        for (int64_t i = a; i < b; i++) acc += in[i];
-        part[t + 1] = acc;
+        /* the runtime may grant fewer threads than asked for (OMP_THREAD_LIMIT, dynamic teams): chunks are dealt to the team
+         * that actually runs, never indexed by the thread number alone */
+        const int me = omp_get_thread_num(), team = omp_get_num_threads();
+        for (int t = me; t < nthreads; t += team) {
+            const int64_t a = t * chunk < n ? t * chunk : n, b = a + chunk < n ? a + chunk : n;
+            uint32_t acc = 0;
+            for (int64_t i = a; i < b; i++) acc += in[i];
+            part[t + 1] = acc;
+        }
 #pragma omp barrier
 #pragma omp single
         for (int k = 0; k < nthreads; k++) part[k + 1] += part[k];
-        acc = part[t];
-        for (int64_t i = a; i < b; i++) { acc += in[i]; out[i] = acc; }
+        for (int t = me; t < nthreads; t += team) {
+            const int64_t a = t * chunk < n ? t * chunk : n, b = a + chunk < n ? a + chunk : n;
+            uint32_t acc = part[t];
+            for (int64_t i = a; i < b; i++) { acc += in[i]; out[i] = acc; }
+        }
     }
     free(part);
 }
@@ -383,10 +390,14 @@ static void sort_pairs_mt(int64_t n, const uint64_t *kin, const uint32_t *vin, u
     const int64_t chunk = (n + nthreads - 1) / nthreads;
 #pragma omp parallel num_threads(nthreads)
     {
-        const int t = omp_get_thread_num();
-        const int64_t a = t * chunk < n ? t * chunk : n, b = a + chunk < n ? a + chunk : n;
-        memcpy(ka + a, kin + a, sizeof(uint64_t) * (size_t)(b - a));
-        memcpy(va + a, vin + a, sizeof(uint32_t) * (size_t)(b - a));
+        /* `nthreads` chunks, dealt to whatever team the runtime grants (see inclusive_scan_u32_mt) */
+        const int me = omp_get_thread_num(), team = omp_get_num_threads();
+#define CHUNK_BOUNDS(t) const int64_t a = (t) * chunk < n ? (t) * chunk : n, b = a + chunk < n ? a + chunk : n
+        for (int t = me; t < nthreads; t += team) {
+            CHUNK_BOUNDS(t);
+            memcpy(ka + a, kin + a, sizeof(uint64_t) * (size_t)(b - a));
+            memcpy(va + a, vin + a, sizeof(uint32_t) * (size_t)(b - a));
+        }
 #pragma omp barrier
         for (int shift = 0; shift < end_bit; shift += 8) {
             const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
@@ -395,9 +406,12 @@ static void sort_pairs_mt(int64_t n, const uint64_t *kin, const uint32_t *vin, u
             const uint32_t *vs = ((shift / 8) & 1) ? vb : va;
             uint64_t *kd = ((shift / 8) & 1) ? ka : kb;
             uint32_t *vd = ((shift / 8) & 1) ? va : vb;
-            int64_t *mine = cnt + 256 * (size_t)t;
-            memset(mine, 0, sizeof(int64_t) * 256);
-            for (int64_t i = a; i < b; i++) mine[(ks[i] >> shift) & mask]++;
+            for (int t = me; t < nthreads; t += team) {
+                CHUNK_BOUNDS(t);
+                int64_t *mine = cnt + 256 * (size_t)t;
+                memset(mine, 0, sizeof(int64_t) * 256);
+                for (int64_t i = a; i < b; i++) mine[(ks[i] >> shift) & mask]++;
+            }
 #pragma omp barrier
 #pragma omp single
             {
@@ -405,26 +419,34 @@ static void sort_pairs_mt(int64_t n, const uint64_t *kin, const uint32_t *vin, u
                 for (int d = 0; d < 256; d++)
                     for (int k = 0; k < nthreads; k++) { const int64_t c = cnt[256 * (size_t)k + d]; cnt[256 * (size_t)k + d] = run; run += c; }
             }
-            for (int64_t i = a; i < b; i++) {
-                const int64_t dst = mine[(ks[i] >> shift) & mask]++;
-                kd[dst] = ks[i];
-                vd[dst] = vs[i];
+            for (int t = me; t < nthreads; t += team) {
+                CHUNK_BOUNDS(t);
+                int64_t *mine = cnt + 256 * (size_t)t;
+                for (int64_t i = a; i < b; i++) {
+                    const int64_t dst = mine[(ks[i] >> shift) & mask]++;
+                    kd[dst] = ks[i];
+                    vd[dst] = vs[i];
+                }
             }
 #pragma omp barrier
         }
         const int passes = (end_bit + 7) / 8;
         const uint64_t *kf = (passes & 1) ? kb : ka;
         const uint32_t *vf = (passes & 1) ? vb : va;
-        memcpy(kout + a, kf + a, sizeof(uint64_t) * (size_t)(b - a));
-        memcpy(vout + a, vf + a, sizeof(uint32_t) * (size_t)(b - a));
+        for (int t = me; t < nthreads; t += team) {
+            CHUNK_BOUNDS(t);
+            memcpy(kout + a, kf + a, sizeof(uint64_t) * (size_t)(b - a));
+            memcpy(vout + a, vf + a, sizeof(uint32_t) * (size_t)(b - a));
+        }
+#undef CHUNK_BOUNDS
     }
     free(ka); free(kb); free(va); free(vb); free(cnt);
 }
 
 /* CR/rasterizer_impl.cu:116-138; ranges must be zeroed first (cudaMemset, :310) */
-void orc_identify_tile_ranges(int64_t L, const uint64_t *keys, uint32_t *ranges)
+static void identify_tile_ranges_mt(int64_t L, const uint64_t *keys, uint32_t *ranges, int nthreads)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int64_t idx = 0; idx < L; idx++) {
         uint32_t currtile = (uint32_t)(keys[idx] >> 32);
         if (idx == 0)
@@ -439,6 +461,8 @@ void orc_identify_tile_ranges(int64_t L, const uint64_t *keys, uint32_t *ranges)
         if (idx == L - 1) ranges[2 * currtile + 1] = (uint32_t)L;
     }
 }
+
+void orc_identify_tile_ranges(int64_t L, const uint64_t *keys, uint32_t *ranges) { identify_tile_ranges_mt(L, keys, ranges, 1); }
 
 /* CR/forward.cu:264-377 (renderCUDA), one 16x16 tile.  The 256-entry staging rounds and the block-wide
  * early exit of the kernel do not change any pixel's arithmetic; each pixel walks the tile list in order
@@ -549,10 +573,7 @@ orc_state *orc_forward(const orc_inputs *in, int nthreads)
     int bit = (int)orc_get_higher_msb((uint32_t)(st->gridx * st->gridy));
     sort_pairs_mt(st->R, st->keys_unsorted, st->vals_unsorted, st->keys, st->vals, 32 + bit, nthreads);
 
-    if (st->R > 0) {
-        omp_set_num_threads(nthreads);
-        orc_identify_tile_ranges(st->R, st->keys, st->ranges);
-    }
+    if (st->R > 0) identify_tile_ranges_mt(st->R, st->keys, st->ranges, nthreads);   /* (no omp_set_num_threads: process-wide) */
 
     const float *feature_ptr = in->colors_precomp ? in->colors_precomp : st->rgb;
     int64_t cf = 0, cb = 0;
@@ -677,6 +698,115 @@ static void render_tile_backward(const orc_inputs *in, const orc_state *st, cons
 #pragma omp atomic
         acc_color[(size_t)id * 3 + 2] += row[8];
     }
+}
+
+/* The ARBITER of the render backward (not a restatement of any reference arithmetic): the same sums as render_tile_backward with
+ * every per-(pixel, entry) term evaluated in DOUBLE -- dx, power, exp, alpha, the transmittance (rebuilt as the forward product
+ * over the contributing entries), the accum_rec recurrence, the nine partial derivatives -- from the float render inputs
+ * (means2D, conic_opacity, colours, dL_dpix, bg) and with the float forward's DECISIONS (which entries a pixel skips, where it
+ * stops: those define the piecewise-smooth function being differentiated and are taken from the float arithmetic above, bit for
+ * bit).  render_tile_backward accumulates in double too, but its terms are the reference's float32 terms, so against it the
+ * reference build shows only its summation error while any other float32 formulation also shows its (equally legitimate)
+ * per-term rounding; against THIS function both show their whole error.  out: rows of 9 doubles per Gaussian:
+ * mean2D.x, .y | conic.x, .y, .w | opacity | colour r g b. */
+static void render_tile_backward_fp64(const orc_inputs *in, const orc_state *st, const float *colors, const float *dL_dpix,
+                                      int tx, int ty, double *out9, double *loc, double *alpha_d /* >= longest list */)
+{
+    const int W = in->W, H = in->H;
+    const uint32_t r0 = st->ranges[2 * (ty * st->gridx + tx)], r1 = st->ranges[2 * (ty * st->gridx + tx) + 1];
+    const int toDo = (int)(r1 - r0);
+    if (toDo <= 0) return;
+    memset(loc, 0, (size_t)toDo * 9 * sizeof(double));
+    for (int ly = 0; ly < BLOCK_Y; ly++)
+        for (int lx = 0; lx < BLOCK_X; lx++) {
+            const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+            if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+            const uint32_t pix_id = W * py + px;
+            const float pixf_x = (float)px, pixf_y = (float)py;
+            const int last_contributor = (int)st->n_contrib[pix_id];
+            /* forward walk: float decisions, double alpha and transmittance; alpha_d[k] < 0 marks a skipped entry */
+            double T = 1.0;
+            for (int k = 0; k < last_contributor && k < toDo; k++) {
+                const uint32_t id = st->vals[r0 + k];
+                const float *co = st->conic_opacity + 4 * id;
+                const float dx = st->means2D[2 * id] - pixf_x, dy = st->means2D[2 * id + 1] - pixf_y;
+                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                alpha_d[k] = -1.0;
+                if (power > 0.0f) continue;
+                const float alpha = fminf_cuda(0.99f, co[3] * expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const double ddx = (double)st->means2D[2 * id] - (double)pixf_x, ddy = (double)st->means2D[2 * id + 1] - (double)pixf_y;
+                const double pw = -0.5 * ((double)co[0] * ddx * ddx + (double)co[2] * ddy * ddy) - (double)co[1] * ddx * ddy;
+                double a = (double)co[3] * exp(pw);
+                if (a > (double)0.99f) a = (double)0.99f;
+                alpha_d[k] = a;
+                T *= 1.0 - a;
+            }
+            const double T_final = T;
+            double accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, bg_dot = 0;
+            for (int i = 0; i < 3; i++) dL_dpixel[i] = (double)dL_dpix[(size_t)i * H * W + pix_id];
+            for (int i = 0; i < 3; i++) bg_dot += (double)in->bg[i] * dL_dpixel[i];
+            for (int k = (last_contributor < toDo ? last_contributor : toDo) - 1; k >= 0; k--) {
+                const double alpha = alpha_d[k];
+                if (alpha < 0) continue;
+                const uint32_t id = st->vals[r0 + k];
+                const float *co = st->conic_opacity + 4 * id;
+                double *row = loc + (size_t)k * 9;
+                const double dx = (double)st->means2D[2 * id] - (double)pixf_x, dy = (double)st->means2D[2 * id + 1] - (double)pixf_y;
+                const double G = exp(-0.5 * ((double)co[0] * dx * dx + (double)co[2] * dy * dy) - (double)co[1] * dx * dy);
+                T = T / (1.0 - alpha);
+                double dL_dalpha = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    const double c = (double)colors[id * 3 + ch];
+                    accum_rec[ch] = last_alpha * last_color[ch] + (1.0 - last_alpha) * accum_rec[ch];
+                    last_color[ch] = c;
+                    dL_dalpha += (c - accum_rec[ch]) * dL_dpixel[ch];
+                    row[6 + ch] += alpha * T * dL_dpixel[ch];
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.0 - alpha)) * bg_dot;
+                const double dL_dG = (double)co[3] * dL_dalpha, gdx = G * dx, gdy = G * dy;
+                row[0] += dL_dG * (-gdx * (double)co[0] - gdy * (double)co[1]) * (0.5 * W);
+                row[1] += dL_dG * (-gdy * (double)co[2] - gdx * (double)co[1]) * (0.5 * H);
+                row[2] += -0.5 * gdx * dx * dL_dG;
+                row[3] += -0.5 * gdx * dy * dL_dG;
+                row[4] += -0.5 * gdy * dy * dL_dG;
+                row[5] += G * dL_dalpha;
+            }
+        }
+    for (int k = 0; k < toDo; k++) {
+        const double *row = loc + (size_t)k * 9;
+        double *dst = out9 + (size_t)st->vals[r0 + k] * 9;
+        for (int c = 0; c < 9; c++)
+            if (row[c] != 0.0) {
+#pragma omp atomic
+                dst[c] += row[c];
+            }
+    }
+}
+
+/* render-level gradient sums in double (see render_tile_backward_fp64); out9 [P][9] must be zero-filled by the caller */
+void orc_render_backward_fp64(const orc_inputs *in, const orc_state *st, const float *dL_dpix, double *out9, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (in->P == 0) return;
+    const float *color_ptr = in->colors_precomp ? in->colors_precomp : st->rgb;
+    const int ntiles = st->gridx * st->gridy;
+    size_t longest = 1;
+    for (int t = 0; t < ntiles; t++) {
+        const size_t len = (size_t)(st->ranges[2 * t + 1] - st->ranges[2 * t]);
+        if (len > longest) longest = len;
+    }
+    double *rows = (double *)malloc(sizeof(double) * 10 * longest * (size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
+    {
+        double *loc = rows + (size_t)omp_get_thread_num() * 10 * longest;
+#pragma omp for schedule(dynamic, 4)
+        for (int t = 0; t < ntiles; t++)
+            render_tile_backward_fp64(in, st, color_ptr, dL_dpix, t % st->gridx, t / st->gridx, out9, loc, loc + 9 * longest);
+    }
+    free(rows);
 }
 
 /* CR/backward.cu:144-274 (computeCov2DCUDA) */

@@ -94,6 +94,11 @@ void orc_backward(const orc_inputs *in, const orc_state *st, const float *dL_dpi
                   float *dL_dsh /*[P,M,3]*/, float *dL_dscale /*[P,3]*/, float *dL_drot /*[P,4]*/,
                   int nthreads);
 
+/* The arbiter for gradient comparisons: the render-level sums (rows of 9 doubles per Gaussian: mean2D.xy, conic.xyw, opacity,
+ * colour rgb) with every per-(pixel, entry) term evaluated in double from the float render inputs, following the float
+ * forward's decisions.  out9 [P][9] must be zero-filled. */
+void orc_render_backward_fp64(const orc_inputs *in, const orc_state *st, const float *dL_dpix, double *out9, int nthreads);
+
 /* CR/rasterizer_impl.cu:54-66,141-153 */
 void orc_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                       uint8_t *present);

@@ -156,8 +156,10 @@ class _Lib(object):
         if h is not None:
             getattr(self.lib, self.prefix + "_free")(h)
 
-    def forward_backward(self, scene, dL_dpix, **kw):
-        """Returns (forward dict, grads dict)."""
+    def forward_backward(self, scene, dL_dpix, exact=False, **kw):
+        """Returns (forward dict, grads dict).  exact=True (plain-C oracle only): grads["exact"] holds the render-level sums
+        dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P,1], dL_dcolor [P,3] as float64 arrays whose per-(pixel, entry) terms
+        were evaluated in double (orc_render_backward_fp64: the arbiter between float32 implementations)."""
         s = scene.as_struct()
         stp = self._call_forward(s, **kw)
         out = self._copy_state(stp.contents, scene)
@@ -168,6 +170,14 @@ class _Lib(object):
             g[name] = np.zeros(shape, dtype=np.float32)
         dpix = _f32(dL_dpix).reshape(3, scene.H, scene.W)
         self._call_backward(s, stp, dpix, g, **kw)
+        if exact:
+            x9 = np.zeros((P, 9), np.float64)
+            self.lib.orc_render_backward_fp64(C.byref(s), stp, dpix.ctypes.data_as(_fp), x9.ctypes.data_as(C.POINTER(C.c_double)),
+                                              C.c_int(kw.get("nthreads", 1)))
+            conic = np.zeros((P, 4), np.float64)
+            conic[:, [0, 1, 3]] = x9[:, 2:5]
+            g["exact"] = dict(dL_dmean2D=np.concatenate([x9[:, 0:2], np.zeros((P, 1))], 1), dL_dconic=conic,
+                              dL_dopacity=x9[:, 5:6].copy(), dL_dcolor=x9[:, 6:9].copy())
         getattr(self.lib, self.prefix + "_free")(stp)
         return out, g
 

@@ -84,7 +84,7 @@ def test_obj_round_trip_and_point_cloud(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------- textured meshes (OBJ + MTL + image)
-def _write_textured_quad(d, flip_second=False):
+def _write_textured_quad(d, flip_second=False, plain_first=False):
     """A unit quad in the z = 0 plane (two triangles, CCW seen from +z) with vt spanning the whole texture, a 4x3 texture whose
     texels are all different, plus a second quad with its own material / texture."""
     from PIL import Image
@@ -96,7 +96,10 @@ def _write_textured_quad(d, flip_second=False):
     tex2 = np.full((2, 2, 3), 255, np.uint8)
     tex2[0, 0] = (255, 0, 0)
     Image.fromarray(tex2).save(str(d / "b.png"))
-    (d / "quad.mtl").write_text("newmtl matA\nKd 1 1 1\nmap_Kd a.png\n\nnewmtl plain\nKd 0.5 0.5 0.5\n\nnewmtl matB\nmap_Kd b.png\n")
+    if plain_first:   # an untextured material BETWEEN the textured ones: the reference's numbering quirk (read_obj docstring)
+        (d / "quad.mtl").write_text("newmtl matA\nKd 1 1 1\nmap_Kd a.png\n\nnewmtl plain\nKd 0.5 0.5 0.5\n\nnewmtl matB\nmap_Kd b.png\n")
+    else:
+        (d / "quad.mtl").write_text("newmtl matA\nKd 1 1 1\nmap_Kd a.png\n\nnewmtl matB\nmap_Kd b.png\n\nnewmtl plain\nKd 0.5 0.5 0.5\n")
     (d / "quad.obj").write_text(
         "mtllib quad.mtl\n"
         "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
@@ -116,11 +119,30 @@ def test_uv_lookup_matches_the_reference_uvmap():
     np.testing.assert_allclose(got, d["result"], rtol=0, atol=1e-12)
 
 
+def test_material_ids_follow_open3d_numbering(tmp_path):
+    """open3d keeps tinyobjloader's material index over ALL materials of the MTL in triangle_material_ids while mesh.textures
+    holds only the materials with a map_Kd, and the reference pairs texture t with material id t (plib/render.py:158-173):
+    with MTL order matA (textured), plain, matB (textured), matB's triangles (id 2) match no texture and come out black.
+    material_numbering='textured' is the repaired numbering."""
+    _write_textured_quad(tmp_path, plain_first=True)
+    mesh = ms.read_obj(str(tmp_path / "quad.obj"))
+    assert len(mesh["textures"]) == 2 and mesh["material_ids"].tolist() == [0, 0, 2, 2]
+    s = ms.sample_uniform(mesh["vertices"], mesh["faces"], 4000, seed=3, triangle_uvs=mesh["triangle_uvs"],
+                          material_ids=mesh["material_ids"], textures=mesh["textures"])
+    right = s["xyz"][:, 0] > 1.5
+    assert right.sum() > 1000 and np.all(s["rgb"][right] == 0.0) and s["rgb"][~right].max() > 0.1
+    fixed = ms.read_obj(str(tmp_path / "quad.obj"), material_numbering="textured")
+    assert fixed["material_ids"].tolist() == [0, 0, 1, 1]
+    # a usemtl the MTL does not define: tinyobjloader's -1
+    (tmp_path / "q2.obj").write_text((tmp_path / "quad.obj").read_text().replace("usemtl matB", "usemtl nowhere"))
+    assert ms.read_obj(str(tmp_path / "q2.obj"))["material_ids"].tolist() == [0, 0, -1, -1]
+
+
 def test_textured_obj_colours_come_from_the_texture(tmp_path):
     tex, tex2 = _write_textured_quad(tmp_path)
     mesh = ms.read_obj(str(tmp_path / "quad.obj"))
     assert mesh["triangle_uvs"].shape == (4, 3, 2) and len(mesh["textures"]) == 2
-    assert mesh["material_ids"].tolist() == [0, 0, 1, 1]          # matA -> texture 0, matB -> texture 1 ('plain' has no map_Kd)
+    assert mesh["material_ids"].tolist() == [0, 0, 1, 1]          # MTL order matA, matB, plain: material id == texture index
     # the image is stored flipped vertically, as open3d's OBJ reader does
     np.testing.assert_array_equal(mesh["textures"][0], tex[::-1].astype(np.float32) / np.float32(255))
     s = ms.sample_uniform(mesh["vertices"], mesh["faces"], 20000, seed=3, triangle_uvs=mesh["triangle_uvs"],

@@ -146,6 +146,33 @@ def test_forward_properties(oracle):
     assert o4["out_color"].tobytes() == o["out_color"].tobytes() and np.array_equal(o4["vals"], o["vals"])
 
 
+def test_threaded_scan_and_sort_survive_a_smaller_team():
+    """the oracle's parallel scan / radix sort cut their input into `nthreads` chunks; when the OpenMP runtime
+    grants a smaller team (OMP_THREAD_LIMIT, dynamic teams) every chunk must still be scanned and scattered.  Runs in a child
+    process (the limit has to be in the environment before libgomp starts): 70 000 Gaussians (>= 65 536: the threaded scan)
+    and > 65 536 pairs (the threaded sort), 8 chunks on a team of at most 3, against the single-thread result."""
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "import util\n"
+        "from oracle.oracle import Oracle\n"
+        "from pcrender import synth\n"
+        "g = synth.random_scene(70000, 96, 64, seed=5, sh_degree=0, spread=1.0, scale=0.01)\n"
+        "s = util.scene_from(g, util.identity_camera(96, 64), 96, 64, bg=(0, 0, 0))\n"
+        "o = Oracle()\n"
+        "a, b = o.forward(s, nthreads=1), o.forward(s, nthreads=8)\n"
+        "assert a['R'] == b['R'] >= 65536, a['R']\n"
+        "for k in ('point_offsets', 'keys', 'vals', 'ranges', 'n_contrib'):\n"
+        "    assert np.array_equal(a[k], b[k]), k\n"
+        "assert a['out_color'].tobytes() == b['out_color'].tobytes()\n"
+        "print('ok', a['R'])\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "gaussian-pcloud-render_amd"))
+    env = dict(os.environ, OMP_THREAD_LIMIT="3", OMP_DYNAMIC="true")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
 def test_empty_and_degenerate_inputs(oracle):
     o = oracle.forward(build_scene("all_culled"))
     s = build_scene("all_culled")

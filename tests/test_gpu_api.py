@@ -232,3 +232,47 @@ def test_concurrent_host_threads_get_the_sequential_result(gpu_device):
     tg.join()
     N.set_profiling(False)
     assert not errs, errs[0]
+
+
+def test_float_aligned_gradient_outputs_take_the_scalar_store_path(gpu_device):
+    """the per-Gaussian backward writes its 3- and 6-float rows (and dL_dsh) as 16-byte chunks from each
+    array's base, which needs 16-byte aligned outputs (include/gsr.h); a C-ABI caller may hand over float-aligned
+    sub-buffers: those are written through per-row stores -- same numbers -- and only dL_drot (one float4 per Gaussian) is
+    refused when misaligned."""
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    s = util.build_scene("sh_deg2")
+    dL = util.seeded_dL(s)
+
+    def t(a):
+        return torch.empty(0) if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = (t(s.bg), t(s.means3D), t(s.colors_precomp), t(s.opacities), t(s.scales), t(s.rotations), s.scale_modifier,
+            t(s.cov3D_precomp), t(s.viewmatrix.reshape(4, 4)), t(s.projmatrix.reshape(4, 4)), s.tanfovx, s.tanfovy, s.H, s.W,
+            t(s.shs), s.sh_degree, t(s.campos), s.prefiltered, False)
+    R, color, radii, geom, binning, img = N.rasterize_gaussians(*args, need_backward=True)
+    bargs = (args[0], args[1], radii, args[2], args[4], args[5], s.scale_modifier, args[7], args[8], args[9], s.tanfovx, s.tanfovy,
+             t(dL), args[14], s.sh_degree, args[16], geom, R, binning, img, False)
+    want = N.rasterize_gaussians_backward(*bargs)
+
+    def shifted(shape, dtype=None, device=None):      # 4 bytes past a 16-byte boundary, except the [P,4] rotation gradient
+        n = int(np.prod(shape))
+        if len(shape) == 2 and shape[1] == 4:
+            return torch.empty(shape, dtype=dtype, device=device)
+        return torch.empty((n + 1,), dtype=dtype, device=device)[1:].view(shape)
+    got = N.rasterize_gaussians_backward_batch(
+        bargs[0], bargs[1], radii.reshape(1, -1), bargs[3], bargs[4], bargs[5], bargs[6], bargs[7], bargs[8].reshape(1, 4, 4),
+        bargs[9].reshape(1, 4, 4), bargs[10], bargs[11], bargs[12].reshape(1, 3, s.H, s.W), bargs[13], bargs[14],
+        bargs[15].reshape(1, 3), geom, binning, img, False, _alloc=shifted)
+    assert got[0].data_ptr() % 16 == 4
+    for a, b in zip(got, want):
+        if a.numel():
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale      # atomics commit in another order between two backwards
+
+    def all_shifted(shape, dtype=None, device=None):
+        return torch.empty((int(np.prod(shape)) + 1,), dtype=dtype, device=device)[1:].view(shape)
+    with pytest.raises(RuntimeError, match="dL_drot must be 16-byte aligned"):
+        N.rasterize_gaussians_backward_batch(
+            bargs[0], bargs[1], radii.reshape(1, -1), bargs[3], bargs[4], bargs[5], bargs[6], bargs[7], bargs[8].reshape(1, 4, 4),
+            bargs[9].reshape(1, 4, 4), bargs[10], bargs[11], bargs[12].reshape(1, 3, s.H, s.W), bargs[13], bargs[14],
+            bargs[15].reshape(1, 3), geom, binning, img, False, _alloc=all_shifted)

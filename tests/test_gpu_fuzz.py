@@ -20,7 +20,10 @@ N_CASES = int(os.environ.get("GSR_FUZZ_CASES", "512"))
 # (float32 conditioning of the per-Gaussian chain), but nothing stops them from being widened until everything passes, so
 # the exits are counted and capped: test_fuzz_escape_hatches_stay_rare fails when more than 1 % of the cases or 1e-4 of the
 # rows compared need one.
-TALLY = dict(cases=0, rows=0, cases_exit_4x_reference=0, rows_exit_4x_reference=0, cases_exit_conditioning=0, rows_exit_conditioning=0)
+# `*_reference_outside_too`: rows outside the plain bar against the float64 value in which the library is at least as close to that
+# value as the reference build is -- the reference itself misses the bar there; recorded, but not an escape of the library.
+TALLY = dict(cases=0, rows=0, cases_exit_4x_reference=0, rows_exit_4x_reference=0, cases_exit_conditioning=0, rows_exit_conditioning=0,
+             cases_reference_outside_too=0, rows_reference_outside_too=0)
 MAX_CASE_FRACTION = 0.01
 MAX_ROW_FRACTION = 1e-4
 
@@ -80,7 +83,7 @@ def test_random_case_matches_reference_build(i, gpu_device):
     assert p["out_color"].tobytes() == r["out_color"].tobytes()
     oracle_grads = None
     TALLY["cases"] += 1
-    used_4x = used_cond = False
+    used_4x = used_cond = used_ref_too = False
     for k, a in gp.items():
         b = gr[k]
         if a.size == 0 and b.size == 0:
@@ -95,15 +98,18 @@ def test_random_case_matches_reference_build(i, gpu_device):
             continue
         # Both sides sum thousands of fp32 terms in different (for the reference: unspecified, atomic) orders, and the
         # per-Gaussian chain conic -> cov3D -> scale / rotation / mean can amplify that rounding noise by 10^3..10^5 on an
-        # ill-conditioned splat (a nearly singular conic).  The plain-C oracle is no arbiter there: it evaluates that chain
-        # in float32 with the reference's own expression order, so it shares the reference build's rounding.  The exact
-        # value comes from the float64 chain of tests/fp64_backward.py fed with the oracle's double-accumulated
-        # render-level sums; the library must be inside the usual bar against it, or no further from it than 4x the
-        # reference build's own distance, row by row.
+        # ill-conditioned splat (a nearly singular conic).  The plain-C oracle's float32 restatement is no arbiter there: it
+        # evaluates every per-(pixel, entry) term and that chain in float32 with the reference's own expression order, so it
+        # shares the reference build's rounding (the double SUMS of those float32 terms lie 2e-7..8e-7 of max|g| from the
+        # true sums on the parity scenes, more than either implementation's summation error).  The exact value comes from
+        # float64 end to end: the oracle's float64 render backward (orc_render_backward_fp64: every term in double, the
+        # float forward's hit / stop decisions) feeding the float64 chain of tests/fp64_backward.py; the library must be
+        # inside the usual bar against it, or no further from it than 4x the reference build's own distance, row by row.
         if oracle_grads is None:
             from oracle.oracle import Oracle
             from fp64_backward import gaussian_backward_fp64
-            of, og = Oracle().forward_backward(s, dL)   # noqa: F841 (of / og are used by the conditioning check below)
+            of, og = Oracle().forward_backward(s, dL, exact=True)   # noqa: F841 (of / og are used by the conditioning check below)
+            og = dict(og, **og["exact"])                              # render-level sums: the float64 ones
             oracle_grads = dict(og)
             oracle_grads.update(gaussian_backward_fp64(s, of["radii"], of["clamped"], og["dL_dmean2D"], og["dL_dconic"], og["dL_dcolor"]))
         o = np.asarray(oracle_grads[k], np.float64).reshape(a.shape[0], -1)
@@ -112,11 +118,15 @@ def test_random_case_matches_reference_build(i, gpu_device):
         r_lib, r_build = np.linalg.norm(a2 - o, axis=1), np.linalg.norm(b2 - o, axis=1)
         plain = r_lib <= util.ROW_REL * rn + util.ROW_ABS * rn.max() + 1e-30          # the usual row bar, against the exact value
         ok = r_lib <= np.maximum(util.ROW_REL * rn + util.ROW_ABS * rn.max(), 4 * r_build) + 1e-30
-        n4 = int((ok & ~plain).sum())
+        no_worse = ~plain & (r_lib <= r_build)          # the reference build is outside the bar too, and further out
+        if no_worse.any():
+            used_ref_too = True
+            TALLY["rows_reference_outside_too"] += int(no_worse.sum())
+        n4 = int((ok & ~plain & ~no_worse).sum())
         if n4:
             used_4x = True
             TALLY["rows_exit_4x_reference"] += n4
-            w = np.nonzero(ok & ~plain)[0]
+            w = np.nonzero(ok & ~plain & ~no_worse)[0]
             print("fuzz exit (4x reference): case %d %s rows %s: lib-exact %s, ref-exact %s, row bar %s" % (
                 i, k, w.tolist()[:4], r_lib[w][:4], r_build[w][:4], (util.ROW_REL * rn + util.ROW_ABS * rn.max())[w][:4]))
         if not ok.all() and k in ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
@@ -150,6 +160,7 @@ def test_random_case_matches_reference_build(i, gpu_device):
             i, k, int((~ok).sum()), r_lib[~ok].max(), r_build[~ok][np.argmax(r_lib[~ok])], d_ref, scale)
     TALLY["cases_exit_4x_reference"] += int(used_4x)
     TALLY["cases_exit_conditioning"] += int(used_cond)
+    TALLY["cases_reference_outside_too"] += int(used_ref_too and not (used_4x or used_cond))
 
 
 def test_fuzz_escape_hatches_stay_rare():

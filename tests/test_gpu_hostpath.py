@@ -115,6 +115,49 @@ def test_rasterize_views_makes_one_readback_and_no_torch_sync(gpu_device):
         rasterize_views(L["means3D"], L["means2D"], L["opacities"], s_bad, shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
 
 
+def test_view_block_cache_keys_on_strides_and_survives_inference_tensors(gpu_device):
+    """(1) cameras built under torch.inference_mode() have no version counter -- rasterize_views must not
+    crash, it packs their blocks per call; (2) M and M.T share address and version but not strides: they are different
+    cameras and must not collide on one cache entry; (3) set_view_cache(False) packs on every call (the remedy for writes
+    that bypass the version counter, `m.data.copy_`)."""
+    from diff_gaussian_rasterization import rasterize_views
+    import diff_gaussian_rasterization as d
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=2)
+    L = leaves()
+
+    def render(sl):
+        with torch.no_grad():
+            return rasterize_views(L["means3D"], L["means2D"], L["opacities"], sl, shs=L["shs"], scales=L["scales"],
+                                   rotations=L["rotations"])[0].clone()
+    ref = render(settings)
+    # (1) inference tensors
+    with torch.inference_mode():
+        s_inf = [s._replace(viewmatrix=s.viewmatrix.clone(), projmatrix=s.projmatrix.clone(), campos=s.campos.clone())
+                 for s in settings]
+    n0 = len(d._VIEW_BLOCKS)
+    assert torch.equal(render(s_inf), ref)
+    assert len(d._VIEW_BLOCKS) == n0, "a settings list with inference tensors must bypass the cache"
+    # (2) a transposed alias of the same storage is another camera
+    m = settings[0].viewmatrix.reshape(4, 4)
+    s_t = [settings[0]._replace(viewmatrix=m.t()), settings[1]]
+    want = render([settings[0]._replace(viewmatrix=m.t().contiguous()), settings[1]])
+    render(settings)                       # make sure the untransposed entry is the cached one
+    got = render(s_t)
+    assert torch.equal(got, want) and not torch.equal(got, ref)
+    # (3) cache off: a write that bypasses the version counter is seen
+    d.set_view_cache(False)
+    try:
+        s_w = [s._replace(viewmatrix=s.viewmatrix.clone()) for s in settings]
+        a = render(s_w)
+        s_w[0].viewmatrix.data.copy_(m.t().contiguous().reshape(s_w[0].viewmatrix.shape))
+        b = render(s_w)
+        assert torch.equal(a, ref) and torch.equal(b, want)
+        assert len(d._VIEW_BLOCKS) == 0
+    finally:
+        d.set_view_cache(True)
+
+
 def test_repeated_backward_returns_the_same_gradients(gpu_device):
     from diff_gaussian_rasterization import GaussianRasterizer, rasterize_views
     dev = gpu_device
