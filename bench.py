@@ -62,22 +62,67 @@ STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_ren
                 "preprocess_backward": "k_preprocess_backward<1>", "duplicate": "k_duplicate<unsigned short>"}
 
 
-def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes):
-    """Minimum HBM bytes each step of the pipeline has to move (per frame).  Render / preprocess figures are
-    SURVEY.md 8(d)'s; the sort figures follow this library's own data flow (u32 depth keys and ids; tile keys are
-    u16 for images of up to 65536 tiles)."""
+def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes, views_per_call=1):
+    """Minimum HBM bytes each stage has to move PER FRAME when `views_per_call` views of one cloud travel in one submission.
+    Render / preprocess figures are SURVEY.md 8(d)'s per-view formulas with what a batched launch shares counted once per batch:
+    the per-Gaussian inputs of preprocess ((44 + 12 K) P) and of the per-Gaussian backward ((107 + 12 K) V) are read once for all
+    views, and the backward's outputs ((40 + 12 K) V) are written once (summed over the views in registers).  The sort figures
+    follow this library's own data flow (u32 depth keys and ids; tile keys are u16 for images of up to 65 536 tiles); the tile
+    ranges are found by binary search (about 24 two-byte probes per tile), not by a pass over the keys, and the prefix sum of the
+    tile counts is part of the pair emission (no separate scan)."""
     b = {}
     kb = 2 if T <= 65536 else 4
-    b["preprocess"] = (44 + 12 * K) * P + 75 * V + 8 * (P - V)
+    vpc = max(1, int(views_per_call))
+    b["preprocess"] = (44 + 12 * K) * P / vpc + 75 * V + 8 * (P - V)
     b["depth_sort"] = 4 * (4 + 8 + 8) * P
-    b["offsets_scan"] = 3 * 8 * P
     b["duplicate"] = 20 * P + (kb + 4) * R
     b["tile_sort"] = tile_passes * (kb + 2 * (kb + 4)) * R
-    b["tile_ranges"] = kb * R + 16 * T
+    b["tile_ranges"] = (24 * kb + 16) * T
     b["render_forward"] = 40 * C_fwd + 8 * T + 20 * N
     b["render_backward"] = 40 * C_bwd + 20 * N + 44 * V
-    b["preprocess_backward"] = 92 * V + (107 + 12 * K) * V + (40 + 12 * K) * V
+    b["preprocess_backward"] = 92 * V + ((107 + 12 * K) * V + (40 + 12 * K) * V) / vpc
     return b
+
+
+# BASELINE.json configs this bench can run (`--config`); 2 is the headline
+CONFIGS = {
+    1: dict(workload="synth-THuman-256", width=1920, height=1080, forward_only=True, n_views=12, shard="circle",
+            what="configs[1]: THuman-256 (200K voxelised points), 1080p, forward-only"),
+    2: dict(workload="synth-THuman-800K", width=1920, height=1080, forward_only=False, n_views=12, shard="circle",
+            what="configs[2]: THuman-800K, 1080p, forward+backward (the headline)"),
+    3: dict(workload="synth-THuman-800K", width=1920, height=1080, forward_only=False, n_views=8, shard="views",
+            what="configs[3]: THuman-800K, 8 camera views sharded across the ranks, frames gathered on rank 0"),
+    4: dict(workload="synth-mesh-2M", width=3840, height=2160, forward_only=False, n_views=8, shard="views",
+            what="configs[4]: 2M-point sampled mesh, 3840x2160, forward+backward, 8 camera views sharded across the ranks"),
+}
+
+
+def view_of(k, rank, world, n_views, shard):
+    """Camera view of local step k on `rank`.
+    shard "circle" (weak scaling of the headline): every rank walks the whole circle, rank r starting (r n_views) // world views
+    in, so ANY n_views consecutive steps of a rank are n_views distinct views whatever the world size, and at a given step the
+    ranks render different views (world <= n_views).
+    shard "views" (configs[3] / [4]): the n_views views of one turn are dealt round-robin, rank r owns {v : v mod world == r}
+    (pcrender.multiview.shard_views) and walks its own views in order."""
+    if shard == "circle":
+        return (k + (rank * n_views) // world) % n_views
+    mine = list(range(rank, n_views, world)) or [rank % n_views]
+    return mine[k % len(mine)]
+
+
+def union_ms(intervals):
+    """total length of the union of (start, end) intervals"""
+    tot, cur_a, cur_b = 0.0, None, None
+    for a, b in sorted(intervals):
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                tot += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        tot += cur_b - cur_a
+    return tot
 
 
 def main():
@@ -85,17 +130,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="synth-THuman-800K")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[i] (2 = the headline): sets the workload, image size, forward-only and how views are "
+                         "dealt to the ranks; --workload / --width / --height / --forward-only still override")
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--warmup-seconds", type=float, default=0.3,
+                    help="untimed frames are rendered for at least this long on top of --warmup, so that the timed region starts at "
+                         "the clocks the chip sustains (disclosed in warmup_effective)")
+    ap.add_argument("--gather-mode", default="collective", choices=["collective", "p2p"],
+                    help="frame gather to rank 0: one dist.gather per submission, or a grouped irecv / isend per peer "
+                         "(dist.batch_isend_irecv; DESIGN.md section 8)")
     ap.add_argument("--points", type=int, default=None, help="override the point count (debug)")
     ap.add_argument("--profile", default="training", choices=["training", "inference"])
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "12")),
+    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("GSR_BENCH_VIEWS_PER_CALL", "0")),
                     help="frames submitted per rasterizer call: 1 = the reference's per-view GaussianRasterizer call; V > 1 = "
-                         "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission")
+                         "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission; "
+                         "0 = the config's default: 12 (one turn of the circle) for configs 1 / 2, the rank's own views for 3 / 4")
     ap.add_argument("--no-per-view", action="store_true", help="skip the drop-in-API / forward-only / rgb-time side measurements")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="no per-stage hipEvents anywhere (for timeline traces: an event pair costs ~10 us of bubble per stage)")
@@ -111,8 +166,11 @@ def main():
                          "(frames then travel through host memory; not a performance mode)")
     ap.add_argument("--device-index", type=int, default=-1, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
-    if args.streams <= 0:
-        args.streams = 2 if args.steps >= 4 * max(1, args.views_per_call) else 1
+    cfg = CONFIGS[args.config]
+    args.workload = args.workload or cfg["workload"]
+    args.width = args.width or cfg["width"]
+    args.height = args.height or cfg["height"]
+    args.forward_only = args.forward_only or cfg["forward_only"]
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
@@ -155,7 +213,12 @@ def main():
     cloud = synth.make_cloud(args.workload, seed=0, P=args.points)
     g = synth.make_gaussians(cloud, profile=args.profile, seed=1)
     P, M, D = g["means3D"].shape[0], g["shs"].shape[1], g["sh_degree"]
-    n_views = 12
+    n_views, shard = cfg["n_views"], cfg["shard"]
+    if args.views_per_call <= 0:
+        args.views_per_call = n_views if shard == "circle" else max(1, len(range(rank, n_views, world)))
+    if args.streams <= 0:
+        args.streams = 2 if args.steps >= 4 * max(1, args.views_per_call) else 1
+    # the reference's circle cameras (simple_raw_render.py:259-278 loops over them); configs[3] / [4] use 8 of them
     views = camera.circle_views(n_imgs=n_views, fov_deg=45.0, width_px=W, height_px=H)
     bg = torch.ones(3, device=dev)  # simple_benchmark.py:332 background (1,1,1)
     settings = [GaussianRasterizationSettings(
@@ -187,9 +250,28 @@ def main():
     gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
     gather_events = []      # (start, end) on the gather stream, one pair per submission of the timed region
 
+    # ---- instrumentation INSIDE the timed region: two hipEvents around every submission on the stream it runs on (GPU time of the
+    # timed steps themselves, not of a pass taken afterwards) and one shader-clock probe per submission on a side stream (the
+    # clock the chip sustains under exactly this load).  Costs two event records and one 64-lane kernel per submission.
+    sub_events = []          # (tag, start event, end event)
+    sub_tag = [None]         # None: not recording
+    probe = _native.ClockProbe(dev, capacity=1024)
+
+    def bracket(fn):
+        if sub_tag[0] is None:
+            return fn()
+        cur = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        probe.launch()
+        out = fn()
+        e1.record(cur)
+        sub_events.append((sub_tag[0], e0, e1))
+        return out
+
     def render(i, tslot=0, with_grad=True, vpc_views=None):
-        """Forward (+ backward) of global step i on the calling thread's current stream; returns the frame."""
-        v = (i * world + rank) % n_views
+        """Forward (+ backward) of local step i on the calling thread's current stream; returns the frame."""
+        v = view_of(i, rank, world, n_views, shard)
         L = leafsets[tslot]
         if with_grad:
             img, _ = rasterizers[v](**L)
@@ -202,11 +284,14 @@ def main():
         return img
 
     def render_many(i, n, tslot=0, with_grad=True):
-        """Global steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
+        return bracket(lambda: render_many_(i, n, tslot, with_grad))
+
+    def render_many_(i, n, tslot=0, with_grad=True):
+        """Local steps i .. i+n-1 of this rank in ONE rasterizer call (n <= --views-per-call); returns the frames [n,3,H,W]."""
         if n == 1:
             return render(i, tslot, with_grad)[None]
         L = leafsets[tslot]
-        sts = [settings[((i + k) * world + rank) % n_views] for k in range(n)]
+        sts = [settings[view_of(i + k, rank, world, n_views, shard)] for k in range(n)]
         if with_grad:
             imgs, _ = rasterize_views(L["means3D"], L["means2D"], L["opacities"], sts, shs=L["shs"], scales=L["scales"],
                                       rotations=L["rotations"])
@@ -232,7 +317,8 @@ def main():
                 e0.record(gather_stream)
             src = imgs.cpu() if host_collectives else imgs.contiguous()
             src.record_stream(gather_stream) if src.is_cuda else None
-            dist.gather(src, gather_list=[b[:n] for b in gather_bufs] if rank == 0 else None, dst=0)
+            for w in multiview.gather_to_root(src, [b[:n] for b in gather_bufs] if rank == 0 else None, dst=0, mode=args.gather_mode):
+                w.wait()            # (RCCL: orders the gather stream behind the transfer, the host does not block)
             if timing_gather[0]:
                 e1.record(gather_stream)
                 gather_events.append((e0, e1))
@@ -270,10 +356,13 @@ def main():
         """single-stream pass with hipEvents around every stage; returns ({stage: mean ms per launch}, wall seconds)"""
         torch.cuda.synchronize()
         _native.set_profiling(True)
+        sub_tag[0] = "stage"          # (the shader-clock probes run beside this pass too)
         t1 = time.perf_counter()
         run_steps(warm, count, streams=1, gather_on=False, **kw)
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
+        sub_tag[0] = None
+        sub_events.clear()
         ms = {}
         for name, t in _native.get_profile():
             ms.setdefault(name, []).append(t)
@@ -281,28 +370,89 @@ def main():
         return {k: float(np.mean(v)) for k, v in ms.items()}, d1
 
     # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
-    # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing
+    # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing,
+    # plus frames until --warmup-seconds have passed: the chip settles at the clock it sustains under this load
     warm = max(args.warmup, 3 * max(1, args.streams))
+    t_w = time.perf_counter()
     run_steps(0, max(warm, VPC * max(1, args.streams) * 2), streams=1)      # primes the caller's stream and allocator pool
     run_steps(0, max(warm, VPC * max(1, args.streams) * 2))
+    warm_steps = 2 * max(warm, VPC * max(1, args.streams) * 2)
+    torch.cuda.synchronize()
+    more = torch.zeros(1, dtype=torch.int32)
+    while True:
+        # every rank must run the same number of warm-up rounds (they contain collectives): rank 0's clock decides
+        more[0] = int(time.perf_counter() - t_w < args.warmup_seconds)
+        if use_dist:
+            mt = more.to("cpu" if host_collectives else dev)
+            dist.broadcast(mt, src=0)
+            more.copy_(mt)
+        if not int(more[0]):
+            break
+        run_steps(0, max(args.steps, VPC))
+        warm_steps += max(args.steps, VPC)
+        torch.cuda.synchronize()
+    # first use of the in-region instrumentation happens HERE, not in the first timed block: the probe kernel's code object is
+    # loaded on its first launch and torch grows its event pool (7 ms in the first block otherwise)
+    sub_tag[0] = "warm"
+    run_steps(0, max(args.steps, VPC))
+    sub_tag[0] = None
+    warm_steps += max(args.steps, VPC)
+    torch.cuda.synchronize()
+    sub_events.clear()
+    warm_seconds = time.perf_counter() - t_w
     fence()
+    # Python's cyclic garbage collector is kept out of the timed region, as timeit does: a generation-2 collection is a 30 ms host
+    # stall (it landed in the second submission of the third block of every --steps 20 run: 34 ms instead of 4.6); collected now
+    import gc
+    gc.collect()
+    gc.disable()
     block_dt = []
+    block_base = []          # one event per timed block, recorded on the caller's stream when the block starts
+    tail_events = []         # per block: (last render work done, last gather done) -> the gather time nothing hides
     nxt = warm
     timing_gather[0] = True
-    for _ in range(max(1, args.repeats)):
+    probe_first = probe.n
+    for b in range(max(1, args.repeats)):
+        base = torch.cuda.Event(enable_timing=True)
+        base.record(torch.cuda.current_stream(dev))
+        block_base.append(base)
+        sub_tag[0] = b
         t0 = time.perf_counter()
         run_steps(nxt, args.steps)
+        sub_tag[0] = None
+        if do_gather:
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(torch.cuda.current_stream(dev))       # behind every submission of the block (run_steps joined its workers)
+            eb.record(gather_stream)
+            tail_events.append((ea, eb))
         fence()
         block_dt.append(time.perf_counter() - t0)
         nxt += args.steps
     timing_gather[0] = False
+    gc.enable()
+    sclk_timed = probe.mhz(probe_first)
     gather_ms = [float(a.elapsed_time(b)) for a, b in gather_events] if gather_events else None
+    gather_exposed_ms = [max(0.0, float(a.elapsed_time(b))) for a, b in tail_events] if tail_events else None
+    # GPU time of the timed steps: the union of the submissions' [start, end] intervals on the device clock, per block
+    gpu_busy_ms, sub_ms = [], []
+    for b in range(len(block_dt)):
+        iv = [(float(block_base[b].elapsed_time(e0)), float(block_base[b].elapsed_time(e1))) for tag, e0, e1 in sub_events if tag == b]
+        gpu_busy_ms.append(union_ms(iv))
+        sub_ms.append([round(b1 - a1, 3) for a1, b1 in sorted(iv)])
+    sub_events.clear()
+    block_dt_local = list(block_dt)
 
     avg_ms, single = {}, None
+    sclk_stage = []
     per_view = drop_in = fwd_only = rgb_time = None
     if rank == 0 and not args.no_stage_events:
-        n1 = max(min(args.steps, 24), VPC)
+        # whole --views-per-call submissions only: `kernels_ms` is a mean per LAUNCH and is divided by the views of a launch below
+        # (a pass that mixed 12- and 8-view launches understated every per-frame figure by 17 %: the driver's --steps 20 run of
+        # round 3 and its "18 % faster kernels")
+        n1 = 2 * VPC
+        probe_stage = probe.n
         avg_ms, d1 = stage_pass(n1)
+        sclk_stage = probe.mhz(probe_stage)
         single = {"frames_per_s": round(n1 / d1, 3), "ms_per_frame": round(d1 / n1 * 1e3, 4), "frames": n1,
                   "note": "one submission in flight, hipEvents around every stage (each pair costs ~10 us of bubble)"}
     if rank == 0 and not args.no_per_view and not args.no_stage_events:
@@ -355,15 +505,20 @@ def main():
                     rgb_time.setdefault("iterations_ms", {})[name] = [round(x, 2) for x in its]
         except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
             rgb_time = {"error": repr(ex)}
+    per_rank_blocks = None
     if use_dist:
-        t = torch.tensor(block_dt, device="cpu" if host_collectives else dev, dtype=torch.float64)
+        cdev = "cpu" if host_collectives else dev
+        t = torch.tensor(block_dt, device=cdev, dtype=torch.float64)
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                            # each rank's own block times (before the MAX): per-rank frames/s
+        per_rank_blocks = [[float(x) for x in e.tolist()] for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         block_dt = [float(x) for x in t.tolist()]
     dt = float(np.median(block_dt))
 
     if rank == 0:
         # ---- workload statistics for the bytes model, averaged over the views rank 0 rendered
-        used = sorted({((warm + i) * world) % n_views for i in range(args.steps * max(1, args.repeats))})
+        used = sorted({view_of(warm + i, 0, world, n_views, shard) for i in range(args.steps * max(1, args.repeats))})
         stats = dict(V=0.0, R=0.0, C_fwd=0.0, C_bwd=0.0)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         with torch.no_grad():
@@ -389,7 +544,7 @@ def main():
                     stats["C_bwd"] += float(cb) / len(used)
         tile_bits = int(T).bit_length()
         bytes_per = algorithmic_bytes(P, stats["V"], stats["R"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
-                                      (tile_bits + 7) // 8)
+                                      (tile_bits + 7) // 8, views_per_call=VPC)
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
         roofline = None
         # HBM bytes / VALU instructions / kernel duration per launch from the committed rocprofv3 passes -- only if they were taken
@@ -427,7 +582,16 @@ def main():
                     roofline["profile_avg_ms"] = round(pa / 1e3, 4)
                     roofline["frac_profile"] = round(bytes_per[dom] * VPC / (pa * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
                     rel = avg_ms[dom] / (pa / 1e3)
-                    roofline["live_vs_profile"] = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
+                    lv = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
+                    # the same kernel on another box / in a profiled pass runs at another clock: compare CYCLES (ms x shader clock)
+                    pclk = pmc.get("sclk_mhz")
+                    if pclk and sclk_stage:
+                        lclk = float(np.median(sclk_stage))
+                        reln = rel * lclk / float(pclk)
+                        lv.update({"sclk_mhz_live": round(lclk, 1), "sclk_mhz_profile": round(float(pclk), 1),
+                                   "ratio_clock_normalised": round(reln, 3),
+                                   "agree_within_10pct_clock_normalised": bool(abs(reln - 1.0) <= 0.10)})
+                    roofline["live_vs_profile"] = lv
                 valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
                 if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
                     rate = valu / (avg_ms[dom] * 1e-3)
@@ -493,11 +657,32 @@ def main():
                       "rendered frames/sec %dx%d (%s)" % (W, H, "fwd+bwd" if grad else "fwd"),
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "repeats": len(block_dt),
             "ms_per_step_blocks": [round(x / args.steps * 1e3, 4) for x in block_dt],
-            "warmup": args.warmup, "warmup_effective": 2 * max(warm, VPC * max(1, args.streams) * 2), "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup,
+            "warmup_effective": {"steps": int(warm_steps), "seconds": round(warm_seconds, 3),
+                                 "note": "--warmup steps, allocator / stream priming, then whole blocks until --warmup-seconds "
+                                         "(%.2f) had passed; all untimed" % args.warmup_seconds},
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "python_gc": "collected before, disabled inside the timed region (like timeit)",
+            # GPU time of the TIMED steps themselves (rank 0): per block, the union of the submissions' [start, end] hipEvent
+            # intervals on the streams they ran on (loss kernels included), and the block's wall time over it
+            "gpu_ms_per_step_timed": round(float(np.median(gpu_busy_ms)) / args.steps, 4) if gpu_busy_ms else None,
+            "gpu_ms_per_step_timed_blocks": [round(x / args.steps, 4) for x in gpu_busy_ms],
+            "gpu_ms_submissions_blocks": sub_ms if sum(len(x) for x in sub_ms) <= 64 else None,   # per block, every submission's own span
+            "wall_over_gpu": round(float(np.median([w * 1e3 / g for w, g in zip(block_dt_local, gpu_busy_ms) if g > 0])), 4)
+            if gpu_busy_ms and all(g > 0 for g in gpu_busy_ms) else None,
+            "sclk_mhz": {"timed_region": round(float(np.median(sclk_timed)), 1) if sclk_timed else None,
+                         "timed_region_min_max": [round(min(sclk_timed), 1), round(max(sclk_timed), 1)] if sclk_timed else None,
+                         "stage_pass": round(float(np.median(sclk_stage)), 1) if sclk_stage else None,
+                         "probes": len(sclk_timed) + len(sclk_stage),
+                         "how": "one-wave probe kernel per submission on a side stream, beside the frame's kernels: s_memtime "
+                                "(shader cycles) over s_memrealtime (%d kHz)" % probe.khz},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d); %s; view-sharded%s" % (
+            "config": {"workload": "%s %dx%d %s, %d circle views, %s profile, SH degree %d (M=%d); %s; %s%s" % (
                 args.workload, W, H, "fwd+bwd" if grad else "fwd", n_views, args.profile, D, M, shape,
+                "every rank walks the circle, rank r starting (r x %d) // world views in" % n_views if shard == "circle" else
+                "the %d views of a turn dealt round-robin to the ranks (rank r owns v mod world == r)" % n_views,
                 " + RCCL frame gather on its own stream" if do_gather else ""),
+                "baseline_config": cfg["what"],
                 "call_shape": {"views_per_call": VPC, "calls_in_flight": args.streams,
                                "entry_point": "rasterize_views" if VPC > 1 else "GaussianRasterizer.forward"},
                 "points": P, "num_rendered_avg": int(stats["R"]), "visible_avg": int(stats["V"]),
@@ -516,8 +701,13 @@ def main():
                           "frac_of_6300": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4) if frame_gpu_ms else None},
         }
         if use_dist:
+            out["per_rank_frames_per_s"] = [round(args.steps / float(np.median(b)), 1) for b in per_rank_blocks]
             out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                   "gather": None if not gather_ms else {
+                                      "mode": args.gather_mode,
+                                      "exposed_ms_per_block": [round(x, 4) for x in gather_exposed_ms] if gather_exposed_ms else None,
+                                      "exposed_note": "hipEvent time from the end of a block's last submission to the end of its last "
+                                                      "gather on rank 0: the part of the gather no render kernel hides",
                                       "collectives": len(gather_ms), "bytes_into_rank0_per_collective": int((world - 1) * VPC * 3 * H * W * 4),
                                       "ms_mean": round(float(np.mean(gather_ms)), 4), "ms_max": round(float(np.max(gather_ms)), 4),
                                       "note": "hipEvents on the gather stream around each dist.gather (includes waiting for the peers' "

@@ -462,6 +462,25 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 
 // ---- inspection (tests / roofline report only) -------------------------------------------------------
 namespace {
+// One wave reads the shader clock (s_memtime: one tick per shader cycle) and the constant-rate wall clock (s_memrealtime) around a
+// fixed chain of dependent FMAs: delta(shader) / delta(wall) x the wall clock rate is the shader clock the chip is running at
+// while the probe is resident -- next to whatever else is on the device (DVFS follows the power budget, so a kernel time means
+// little without the clock it was measured at).
+__global__ void k_clock_probe(unsigned long long* out, int iters)
+{
+    const unsigned long long s0 = clock64(), w0 = wall_clock64();
+    float x = (float)threadIdx.x * 1e-3f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) x = __builtin_fmaf(x, 0.999f, 1e-3f);
+    }
+    const unsigned long long s1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[0] = s1 - s0;
+        out[1] = w1 - w0;
+    }
+    if (x == 12345.678f) out[1] = 0;   // keeps the chain
+}
 __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const uint8_t* __restrict__ clamped,
                         const uint32_t* __restrict__ k, int key16, const uint32_t* __restrict__ v, void* __restrict__ dst)
 {
@@ -576,6 +595,21 @@ int gsr_selftest(gsr_stream_t stream)
     for (int64_t i = 0; i < n; i++)
         if (gv[i] != order[i] || gk[i] != hk[order[i]]) return fail(GSR_ERR_HIP, "[gsr] selftest: radix sort differs from std::stable_sort at %lld", (long long)i);
     return GSR_OK;
+}
+
+int gsr_clock_probe_launch(void* dst16, int iters, gsr_stream_t stream)
+{
+    if (!dst16 || iters < 1) return fail(GSR_ERR_INVALID, "[gsr] clock probe: bad argument");
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)dst16, iters);
+    if (hipGetLastError() != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] clock probe launch failed");
+    return GSR_OK;
+}
+
+int gsr_wall_clock_khz(void)
+{
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
 }
 
 void gsr_set_profiling(int on)

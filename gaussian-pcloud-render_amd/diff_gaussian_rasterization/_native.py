@@ -32,7 +32,8 @@ class GsrParams(C.Structure):
 # every symbol include/gsr.h declares (tests check the library exports all of them)
 SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
-           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count")
+           "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
+           "gsr_clock_probe_launch", "gsr_wall_clock_khz")
 
 GSR_RETRY = 1
 
@@ -87,6 +88,10 @@ def _load():
     lib.gsr_selftest.argtypes = [_fp]
     lib.gsr_d2h_count.restype = C.c_longlong
     lib.gsr_d2h_count.argtypes = []
+    lib.gsr_clock_probe_launch.restype = C.c_int
+    lib.gsr_clock_probe_launch.argtypes = [_fp, C.c_int, _fp]
+    lib.gsr_wall_clock_khz.restype = C.c_int
+    lib.gsr_wall_clock_khz.argtypes = []
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
     return lib
@@ -317,8 +322,8 @@ def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scale
     dL_dmeans3D = e_or_z((P, 3), **z)
     dL_dcov3D = e_or_z((P, 6), **z)
     dL_dsh = e_or_z((P, M, 3), **z)
-    dL_dscales = torch.empty((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
-    dL_drotations = torch.empty((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
+    dL_dscales = e_or_z((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
+    dL_drotations = e_or_z((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -412,6 +417,38 @@ def grad_records(geom, P, view=0, n_views=1):
         raise RuntimeError("grad_records: not a need_backward geometry arena of %d views" % n_views)
     off = n_views * g_stride + view * gr_stride
     return geom[off:off + P * 64].view(torch.float32).view(P, 16).clone()
+
+
+class ClockProbe:
+    """Shader-clock readings under load (bench / profiles): launch() enqueues the library's one-wave probe kernel on a side
+    stream of its own, next to whatever the device is running; mhz() waits for the probes and returns one effective shader
+    clock per launch, in MHz (include/gsr.h gsr_clock_probe_launch)."""
+
+    def __init__(self, device, capacity=256, iters=256):
+        import threading
+        self.device, self.iters, self.n, self._mu = device, int(iters), 0, threading.Lock()
+        with torch.cuda.device(device):
+            self.buf = torch.zeros((capacity, 2), dtype=torch.int64, device=device)
+            self.stream = torch.cuda.Stream(device=device)
+            self.khz = int(lib.gsr_wall_clock_khz())
+        torch.cuda.synchronize(device)
+
+    def launch(self):
+        with self._mu:
+            if self.n >= self.buf.shape[0]:
+                return
+            slot = self.n
+            self.n += 1
+        with torch.cuda.device(self.device):
+            _check(lib.gsr_clock_probe_launch(self.buf.data_ptr() + 16 * slot, self.iters, self.stream.cuda_stream))
+
+    def mhz(self, first=0):
+        """effective shader clock of probes first .. n-1 (MHz); [] when the wall clock rate is unknown"""
+        self.stream.synchronize()
+        rows = self.buf[first:self.n].cpu().numpy()
+        if self.khz <= 0:
+            return []
+        return [float(s) / float(w) * self.khz / 1e3 for s, w in rows if w > 0]
 
 
 def selftest(device):

@@ -19,12 +19,37 @@ def max_shard(n_views, world):
     return (n_views + world - 1) // world
 
 
-def gather_frames(local_frames, n_views, dst=0, group=None):
+def gather_to_root(src, bufs, dst=0, group=None, mode="collective"):
+    """One frame-gather step: every rank's `src` lands in bufs[rank] on `dst` (bufs: list of world tensors shaped like src on dst,
+    None elsewhere).
+
+    mode "collective": torch.distributed.gather -- one RCCL collective; how it drives the links is the library's business.
+    mode "p2p": the root posts one receive per peer and every peer one send, all in ONE batch_isend_irecv group
+        (ncclGroupStart / ncclRecv x (world - 1) / ncclGroupEnd on RCCL): xGMI is point-to-point, seven direct links end at the root,
+        and a grouped set of receives keeps all of them busy at once even if the collective were implemented as a serial loop
+        over the peers.  The fallback DESIGN.md section 8 names; same result, same call order on every rank.
+    Returns the list of outstanding work handles (empty for "collective"): wait() on them before reading bufs / reusing src."""
+    if mode == "collective":
+        dist.gather(src, gather_list=bufs, dst=dst, group=group)
+        return []
+    if mode != "p2p":
+        raise ValueError("gather mode: 'collective' or 'p2p'")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == dst:
+        bufs[dst].copy_(src)
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst]
+    else:
+        ops = [dist.P2POp(dist.isend, src, dst, group)]
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def gather_frames(local_frames, n_views, dst=0, group=None, mode="collective"):
     """Gather per-rank frame stacks to `dst`.
 
     local_frames: [k_rank, 3, H, W] for the views shard_views(n_views, rank, world) in that order.
     Returns on dst a [n_views, 3, H, W] tensor ordered by view id; None elsewhere.  Shards of unequal length
     (n_views % world != 0) are padded to the longest shard for the collective and trimmed afterwards.
+    mode: see gather_to_root.
     """
     if not (dist.is_available() and dist.is_initialized()):
         return local_frames
@@ -34,7 +59,8 @@ def gather_frames(local_frames, n_views, dst=0, group=None):
     pad = torch.zeros((k,) + shape, dtype=local_frames.dtype, device=local_frames.device)
     pad[: local_frames.shape[0]] = local_frames
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, gather_list=bufs, dst=dst, group=group)
+    for w in gather_to_root(pad, bufs, dst=dst, group=group, mode=mode):
+        w.wait()
     if rank != dst:
         return None
     out = torch.empty((n_views,) + shape, dtype=local_frames.dtype, device=local_frames.device)
@@ -54,7 +80,7 @@ def reduce_gradients(grads, group=None):
     return grads
 
 
-def render_views(render_one, n_views, dst=0, group=None):
+def render_views(render_one, n_views, dst=0, group=None, mode="collective"):
     """render_one(view_id) -> [3,H,W] tensor.  Renders this rank's shard, gathers every frame on `dst`."""
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -63,7 +89,7 @@ def render_views(render_one, n_views, dst=0, group=None):
     frames = [render_one(v) for v in shard_views(n_views, rank, world)]
     if not frames:
         raise ValueError("rank %d owns no view (n_views=%d < world=%d)" % (rank, n_views, world))
-    return gather_frames(torch.stack(frames, 0), n_views, dst=dst, group=group)
+    return gather_frames(torch.stack(frames, 0), n_views, dst=dst, group=group, mode=mode)
 
 
 _STREAMS = {}

@@ -195,6 +195,14 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
 void gsr_set_profiling(int on);
 int gsr_get_profile(const char** names, float* ms, int cap);
 
+/* Shader-clock probe (bench / profiles only): enqueues a one-wave kernel on `stream` that spins through `iters` x 64 dependent FMAs
+ * (about iters x 0.15 us) and stores two 64-bit counts at dst16 (device memory, 16 bytes): elapsed shader-clock ticks (s_memtime) and
+ * elapsed ticks of the constant-rate wall clock (s_memrealtime, gsr_wall_clock_khz() ticks per millisecond).  Their ratio x the wall
+ * rate is the shader clock the device sustained while the probe was resident -- launched on a side stream it reads the clock UNDER
+ * the load of the kernels running beside it.  Nothing in the library waits for it. */
+int gsr_clock_probe_launch(void* dst16, int iters, gsr_stream_t stream);
+int gsr_wall_clock_khz(void);
+
 /* Device self-test of internal primitives (the matrix-core pixel contraction of the render backward, stable radix sort vs std::stable_sort).
  * Allocates its own small buffers; not part of the hot path.  0 = pass. */
 int gsr_selftest(gsr_stream_t stream);

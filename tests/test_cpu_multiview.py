@@ -18,13 +18,13 @@ def _frame(v, H=6, W=10):
     return torch.rand((3, H, W), generator=g)
 
 
-def _worker(rank, world, port, n_views, q):
+def _worker(rank, world, port, n_views, q, mode="collective"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pcrender import multiview
     try:
-        out = multiview.render_views(_frame, n_views, dst=0)
+        out = multiview.render_views(_frame, n_views, dst=0, mode=mode)
         grads = [torch.full((4, 3), float(rank + 1)), None, torch.arange(5, dtype=torch.float32) * (rank + 1)]
         multiview.reduce_gradients(grads)
         ok = True
@@ -41,10 +41,10 @@ def _worker(rank, world, port, n_views, q):
         dist.destroy_process_group()
 
 
-def _run(world, n_views, port):
+def _run(world, n_views, port, mode="collective"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -69,6 +69,13 @@ def test_gather_world2_even():
 
 def test_gather_world3_uneven_shards():
     _run(3, 8, 29632)     # shards of 3,3,2 views: padded for the collective, trimmed on the root
+
+
+def test_gather_p2p_fallback_world2_and_world3():
+    """the grouped send / receive gather (batch_isend_irecv: DESIGN.md section 8's fallback for a root gather that does not
+    drive the seven xGMI links at once) delivers what the collective delivers, even and uneven shards"""
+    _run(2, 12, 29636, mode="p2p")
+    _run(3, 8, 29637, mode="p2p")
 
 
 def test_single_process_passthrough():

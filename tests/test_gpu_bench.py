@@ -30,6 +30,14 @@ def test_single_rank_line_has_the_contract_fields(gpu_device):
     assert d["repeats"] == 5 and len(d["ms_per_step_blocks"]) == 5 and "one_core" in d["cpu_baseline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    # the line explains its own wall time: GPU time of the timed steps from events inside the timed region, the shader clock
+    # under load in the timed region and in the per-stage pass, and the untimed warm-up it really did
+    assert d["gpu_ms_per_step_timed"] > 0 and len(d["gpu_ms_per_step_timed_blocks"]) == 5
+    assert 0.9 < d["wall_over_gpu"] < 50
+    assert d["gpu_ms_per_step_timed"] <= d["ms_per_step"] * 1.02
+    assert 500 < d["sclk_mhz"]["timed_region"] < 3000 and 500 < d["sclk_mhz"]["stage_pass"] < 3000
+    assert d["warmup_effective"]["seconds"] >= 0.3 and d["warmup_effective"]["steps"] >= d["warmup"]
+    assert d["config"]["baseline_config"].startswith("configs[2]")
 
 
 def test_two_ranks_complete(gpu_device):
@@ -48,6 +56,14 @@ def test_rccl_backend_runs_at_world_1(gpu_device):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py"), "29543"], capture_output=True,
                        text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_config3_full_size_frames_through_rccl_at_world_1(gpu_device):
+    """BASELINE configs[3] at full size as far as one GPU goes: 8 x 800K / 1080p frames through pcrender.multiview's gather on the
+    RCCL backend with full-size buffers, both gather modes, frames equal to per-view calls (tests/rccl_config3_worker.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_config3_worker.py"), "29544"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_CONFIG3_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 def test_bench_under_torchrun_one_rank_uses_rccl(gpu_device):
@@ -81,3 +97,20 @@ def test_gpus_flag_self_launch_two_ranks_on_one_gpu_via_gloo(gpu_device):
                         "--no-cpu-baseline", "--repeats", "1"] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert _last_json(r.stdout)["n_gpus"] == 2
+
+
+def test_config3_shape_two_ranks_p2p_gather_on_one_gpu(gpu_device):
+    """BASELINE configs[3]'s shape at a small size: 8 views dealt round-robin to the ranks (4 per rank at world 2, one call per
+    step), frames gathered on rank 0 with the grouped send / receive fallback; the line carries per-rank rates and the exposed
+    gather time."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device-index", "0",
+                        "--no-cpu-baseline", "--repeats", "2", "--config", "3", "--gather-mode", "p2p", "--no-per-view",
+                        "--workload", "synth-THuman-256", "--points", "20000", "--width", "256", "--height", "256", "--steps", "8",
+                        "--warmup", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["call_shape"]["views_per_call"] == 4
+    assert d["config"]["baseline_config"].startswith("configs[3]")
+    assert len(d["per_rank_frames_per_s"]) == 2 and min(d["per_rank_frames_per_s"]) > 0
+    ga = d["distributed"]["gather"]
+    assert ga["mode"] == "p2p" and len(ga["exposed_ms_per_block"]) == 2

@@ -68,6 +68,54 @@ def test_config4_2m_points_4k_backward_vs_reference_build(gpu_device):
     check_grads(gp, gr, "2M/4K vs reference build")
 
 
+def test_config4_eight_views_2m_points_4k_in_one_submission_vs_reference_build(gpu_device):
+    """BASELINE configs[4] in its stated shape on ONE GPU: the 8 camera views of the 2 M-point cloud at 3840x2160, forward +
+    backward, through ONE rasterize_views submission (8 x 2.2 GB of binning arenas, 87 M pairs per view through the 8 + 7-bit
+    u16 tile sort).  Reference side: the caller's per-view loop, simple_raw_render.py:259-278, one reference-build call per view;
+    every frame bit-identical, gradients = the float64 sum of the eight per-view gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, rasterize_views
+    from pcrender import camera, synth
+    ref = _ref()
+    dev = gpu_device
+    cloud = synth.make_cloud("synth-mesh-2M", seed=0)
+    g = synth.make_gaussians(cloud, profile="training", seed=1)
+    W, H, V = 3840, 2160, 8
+    views = camera.circle_views(V, fov_deg=45.0, width_px=W, height_px=H)
+    bg = torch.ones(3, device=dev)
+    settings = [GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=v["tanfovx"], tanfovy=v["tanfovy"], bg=bg, scale_modifier=1.0,
+        viewmatrix=v["viewmatrix"].to(dev), projmatrix=v["projmatrix"].to(dev), sh_degree=g["sh_degree"], campos=v["campos"].to(dev),
+        prefiltered=False, debug=False) for v in views]
+    leaf = lambda a: _t(a, dev).requires_grad_(True)  # noqa: E731
+    m3, shs, op, sc, ro = leaf(g["means3D"]), leaf(g["shs"]), leaf(g["opacities"]), leaf(g["scales"]), leaf(g["rotations"])
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    imgs, radii = rasterize_views(m3, m2, op, settings, shs=shs, scales=sc, rotations=ro)
+    assert imgs.shape == (V, 3, H, W)
+    loss = 0
+    dLs = []
+    for v in range(V):
+        dL = np.random.default_rng(300 + v).uniform(-1, 1, (3, H, W)).astype(np.float32)
+        dLs.append(dL)
+        loss = loss + (imgs[v] * _t(dL, dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    gp = dict(dL_dmean2D=m2.grad.cpu().numpy(), dL_dopacity=op.grad.cpu().numpy().reshape(-1, 1), dL_dmean3D=m3.grad.cpu().numpy(),
+              dL_dsh=shs.grad.cpu().numpy(), dL_dscale=sc.grad.cpu().numpy(), dL_drot=ro.grad.cpu().numpy())
+    imgs_h, radii_h = imgs.detach().cpu().numpy(), radii.cpu().numpy()
+    del imgs, loss
+    torch.cuda.empty_cache()
+    total = None
+    for v, view in enumerate(views):
+        s = util.scene_from(g, view, W, H, bg=(1, 1, 1))
+        r, gr = ref.forward_backward(s, dLs[v])
+        assert r["R"] > 50_000_000
+        np.testing.assert_array_equal(radii_h[v], r["radii"])
+        assert imgs_h[v].tobytes() == r["out_color"].tobytes(), "view %d" % v
+        gr = {k: np.asarray(gr[k], np.float64).reshape(gp[k].shape) for k in gp}
+        total = gr if total is None else {k: total[k] + gr[k] for k in total}
+    check_grads(gp, total, "8 views of 2M/4K in one submission vs the summed reference-build gradients", names=tuple(gp))
+
+
 # ------------------------------------------------------------------------------------------------ configs[0]
 def test_config0_thuman256_native_raster_four_passes_vs_oracle(oracle, gpu_device):
     """The reference's real use (simple_benchmark.py pcrender, THuman-256 voxelised, camera 512x512 x super-sample 2):
