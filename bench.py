@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--warmup-seconds", type=float, default=0.3,
+    ap.add_argument("--warmup-seconds", type=float, default=1.0,
                     help="untimed frames are rendered for at least this long on top of --warmup, so that the timed region starts at "
                          "the clocks the chip sustains (disclosed in warmup_effective)")
     ap.add_argument("--gather-mode", default="collective", choices=["collective", "p2p"],
@@ -356,6 +356,8 @@ def main():
         """single-stream pass with hipEvents around every stage; returns ({stage: mean ms per launch}, wall seconds)"""
         torch.cuda.synchronize()
         _native.set_profiling(True)
+        ovl_was = _native._OVERLAP_ON
+        _native.set_overlap(False)    # per-stage times are taken in stream order: one kernel on the device at a time
         sub_tag[0] = "stage"          # (the shader-clock probes run beside this pass too)
         t1 = time.perf_counter()
         run_steps(warm, count, streams=1, gather_on=False, **kw)
@@ -363,6 +365,7 @@ def main():
         d1 = time.perf_counter() - t1
         sub_tag[0] = None
         sub_events.clear()
+        _native.set_overlap(ovl_was)
         ms = {}
         for name, t in _native.get_profile():
             ms.setdefault(name, []).append(t)
@@ -406,17 +409,23 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    run_steps(0, max(args.steps, VPC))      # the collection left the GPU idle for tens of ms: back to the clock under load
+    warm_steps += max(args.steps, VPC)
+    fence()
     block_dt = []
     block_base = []          # one event per timed block, recorded on the caller's stream when the block starts
     tail_events = []         # per block: (last render work done, last gather done) -> the gather time nothing hides
     nxt = warm
     timing_gather[0] = True
     probe_first = probe.n
+    probe_block = []
+    _native.OVERLAP_STATS.update(calls=0, overlapped=0)
     for b in range(max(1, args.repeats)):
         base = torch.cuda.Event(enable_timing=True)
         base.record(torch.cuda.current_stream(dev))
         block_base.append(base)
         sub_tag[0] = b
+        probe_block.append(probe.n)
         t0 = time.perf_counter()
         run_steps(nxt, args.steps)
         sub_tag[0] = None
@@ -429,8 +438,12 @@ def main():
         block_dt.append(time.perf_counter() - t0)
         nxt += args.steps
     timing_gather[0] = False
+    overlap_timed = "%d of %d" % (_native.OVERLAP_STATS["overlapped"], _native.OVERLAP_STATS["calls"])
     gc.enable()
     sclk_timed = probe.mhz(probe_first)
+    probe_block.append(probe.n)
+    sclk_blocks = [round(float(np.median(sclk_timed[a - probe_first:b - probe_first])), 1) if b > a else None
+                   for a, b in zip(probe_block[:-1], probe_block[1:])] if sclk_timed else None
     gather_ms = [float(a.elapsed_time(b)) for a, b in gather_events] if gather_events else None
     gather_exposed_ms = [max(0.0, float(a.elapsed_time(b))) for a, b in tail_events] if tail_events else None
     # GPU time of the timed steps: the union of the submissions' [start, end] intervals on the device clock, per block
@@ -460,13 +473,22 @@ def main():
         drop_in = {"call": "GaussianRasterizer(settings_v)(means3D, means2D, opacities, shs=, scales=, rotations=) per view + "
                            "loss.backward() per view" if grad else "GaussianRasterizer(...) per view under no_grad",
                    "frames_per_s": {}}
-        for name, st in (("one_stream", 1), ("four_streams", 4)):
+        # one_stream: ONE caller thread on one stream, prebuilt GaussianRasterizer objects (the settings tensors are the same objects
+        # every turn, so the library may start a view's front end beside the previous view's backward: _native._OnSideStream);
+        # one_stream_in_order: the same with that overlap switched off (what a caller gets who rebuilds the per-view matrices
+        # on the device before every call, like simple_raw_render.py:259-278 does); four_streams: four caller threads
+        for name, st, ovl in (("one_stream", 1, True), ("one_stream_in_order", 1, False), ("four_streams", 4, True)):
             if st > len(leafsets):
                 continue
+            _native.set_overlap(ovl)
+            _native.OVERLAP_STATS.update(calls=0, overlapped=0)
             # every worker stream has to grow its own allocator pool and arenas first: 48 untimed frames, then the median of
             # three blocks of 48 (a single cold block of 48 frames reported 410-700 frames/s for what runs at 1 400)
             run_steps(warm, 48, streams=st, vpc=1, gather_on=False)
             drop_in["frames_per_s"][name] = round(48 / float(np.median([timed(48, streams=st, vpc=1) for _ in range(3)])), 1)
+            if name == "one_stream":
+                drop_in["overlapped_calls"] = "%d of %d" % (_native.OVERLAP_STATS["overlapped"], _native.OVERLAP_STATS["calls"])
+        _native.set_overlap(True)
         pv_ms, _ = stage_pass(24, vpc=1)
         drop_in["kernels_ms_per_frame"] = {k: round(v, 4) for k, v in pv_ms.items()}
         drop_in["kernel_sum_ms_per_frame"] = round(sum(pv_ms.values()), 4)
@@ -663,6 +685,10 @@ def main():
                                          "(%.2f) had passed; all untimed" % args.warmup_seconds},
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "python_gc": "collected before, disabled inside the timed region (like timeit)",
+            "overlap_of_consecutive_calls": {"on": bool(_native._OVERLAP_ON), "calls_overlapped_in_timed_region": overlap_timed,
+                                             "note": "the library starts a call's front end beside the previous call's backward when every "
+                                                     "input tensor is provably unchanged (_native._OnSideStream; GSR_OVERLAP=0 switches it off); "
+                                                     "the per-stage pass below runs in stream order"},
             # GPU time of the TIMED steps themselves (rank 0): per block, the union of the submissions' [start, end] hipEvent
             # intervals on the streams they ran on (loss kernels included), and the block's wall time over it
             "gpu_ms_per_step_timed": round(float(np.median(gpu_busy_ms)) / args.steps, 4) if gpu_busy_ms else None,
@@ -672,6 +698,7 @@ def main():
             if gpu_busy_ms and all(g > 0 for g in gpu_busy_ms) else None,
             "sclk_mhz": {"timed_region": round(float(np.median(sclk_timed)), 1) if sclk_timed else None,
                          "timed_region_min_max": [round(min(sclk_timed), 1), round(max(sclk_timed), 1)] if sclk_timed else None,
+                         "timed_blocks": sclk_blocks,
                          "stage_pass": round(float(np.median(sclk_stage)), 1) if sclk_stage else None,
                          "probes": len(sclk_timed) + len(sclk_stage),
                          "how": "one-wave probe kernel per submission on a side stream, beside the frame's kernels: s_memtime "
@@ -692,6 +719,9 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
             "kernel_timing": "hipEvents on the launch stream, single-stream pass right after the timed region",
             "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},
+            # per stage: algorithmic bytes of a launch (the per-call-shape model of algorithmic_bytes) over its measured duration
+            "kernels_algorithmic_GBps": {k: round(bytes_per[k] * VPC / (v * 1e-3) / 1e9, 1) for k, v in avg_ms.items()
+                                         if k in bytes_per and v > 0},
             "streams_per_rank": args.streams, "single_stream": single,
             "drop_in_api": drop_in, "per_view_api_frames_per_s": per_view,
             "forward_only": fwd_only, "rgb_time_equiv": rgb_time,

@@ -66,8 +66,11 @@ struct ProfTables {
     int event()
     {
         if (used == pool.size()) {
+            // timing events only: no system-scope fence when they are recorded (hipEventRecord's default release writes the L2s back
+            // and invalidates them between two stages, so the kernel behind an event pair started cold: the per-stage pass read
+            // k_render_backward 7-10 % slower than the kernel trace of the same run, profiles/r04_bench_kernel_stats.csv)
             hipEvent_t e;
-            (void)hipEventCreate(&e);
+            if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreate(&e);
             pool.push_back(e);
         }
         return (int)used++;
@@ -126,7 +129,10 @@ static int landing(HostLanding** out)
     if (!h.pinned) {
         if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&h.mapped, h.pinned, 0) != hipSuccess ||
-            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
+            // the event only has to say "the emission kernel has finished": the counters it waits for are stored to fine-grained
+            // (coherent, uncached) host memory and fenced by the kernel itself (__threadfence_system), so the record needs no
+            // system-scope release of the L2s in the middle of the frame
+            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
             h.pinned = nullptr;
             return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
         }

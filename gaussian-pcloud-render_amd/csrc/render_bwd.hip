@@ -20,9 +20,12 @@
 // sixteen v_mfma_f32_16x16x4_f32 per batch of eight entries, exact fp32).  Two global float atomic instructions per
 // batch (36 lanes each, the nine addresses of an entry inside one 64-B record, zero sums skipped) then update the
 // per-Gaussian gradient records: 9 atomics per (quadrant, entry) instead of 9 x 64.
-// Summation order differs from the reference's (undefined) atomic order, the second moments are shifted from the
-// quadrant centre to the splat centre after the sum, and 1/(1-alpha) is v_rcp_f32 (1 ulp); results agree to fp32
-// rounding (tests: <= 2e-4 of max|g| per tensor, observed ~1e-6).
+// Summation order differs from the reference's (undefined) atomic order and the second moments are shifted from the
+// quadrant centre to the splat centre after the sum; T / (1 - alpha) is the reference's division to the last bit but
+// rare boundary cases (v_rcp_f32 + one residual step).  Against the float64 value of the same sums
+// (oracle: orc_render_backward_fp64) the colour and opacity gradients are as accurate as the reference build's, the
+// mean2D / conic gradients 1.8x / 4x its error at the median (3e-7 .. 9e-7 of max|g|): the moments are rounded once per
+// quadrant where the reference rounds every pixel's product on its own (profiles/r04_bwd_accuracy.txt).
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     bg_dot_dpixel += a.bg[0] * dpx0;
     bg_dot_dpixel += a.bg[1] * dpx1;
     bg_dot_dpixel += a.bg[2] * dpx2;
+    const float neg_tfb = -T_final * bg_dot_dpixel;   // the background term of dL_dalpha, times 1 / (1 - alpha) per entry
     mrow[mm_p] = dpx0; mrow[MM_STRIDE + mm_p] = dpx1; mrow[2 * MM_STRIDE + mm_p] = dpx2;
     mm_basis_dpx(am, mrow, lane);
 #ifdef GSR_BWD_EMUL
@@ -520,6 +524,8 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 mask = have ? (mask & (mask - 1)) : 0;
                 ef[k] = (uint32_t)(hi - 1 - j);  // 0-based position of the entry in the tile list
             }
+            // (the list position carried in an eleventh row of the staged record instead of these ~12 scalar instructions per
+            // entry: measured, +-0 -- 0.2353 vs 0.2333 / 0.2394 ms per view, gpurun_out/r4i: the loop does not wait for its scalar unit)
             float Gs[BGRP], alphas[BGRP];
             bool hits[BGRP];
             bool any_lane_hit = false;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
                 const float d = __builtin_fmaf(eb[k], dpx2, __builtin_fmaf(eg[k], dpx1, er[k] * dpx0));
                 const float sn = __builtin_fmaf(last_alpha, last_d - s_rec, s_rec);  // la*last_d + (1-la)*s
                 float dL_dalpha = (d - sn) * Tn;
-                dL_dalpha = __builtin_fmaf(-T_final * rcp, bg_dot_dpixel, dL_dalpha);
+                dL_dalpha = __builtin_fmaf(neg_tfb, rcp, dL_dalpha);   // (-T_final / (1 - alpha)) * bg . dL_dpixel
 #endif
                 // lanes that do not hit contribute exact zeros: every product of phase 2 carries a factor Gh or alpha*T
                 // (dL_dalpha itself stays finite, so 0 * dL_dalpha is 0)

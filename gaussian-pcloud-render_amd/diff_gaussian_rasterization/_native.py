@@ -173,6 +173,128 @@ def reset_capacity_hints():
     _CAP_HINT.clear()
 
 
+
+# ---- consecutive calls overlap on the device (no caller threads) ---------------------------------------------------------
+# A per-view caller issues forward(j), backward(j), forward(j+1), ... on ONE stream, so the device runs them back to back: the
+# tail of a single view's render kernels (a handful of deep list walks on an otherwise idle chip) and the bandwidth-bound front
+# end of the next view never share the GPU.  Four caller threads on four streams get 1.5x out of that overlap (bench.py,
+# drop_in_api.four_streams); the same overlap is available to ONE caller when the library can prove that the next forward does
+# not depend on the work still in flight:
+#   * every forward runs on one of a few internal side streams (rotating), the caller's stream waits (on the device) for it at
+#     the end of the call, so everything the caller enqueues afterwards is ordered behind the results as before;
+#   * the side stream has to wait for the INPUTS only.  An input tensor seen before -- the same Python tensor object with the
+#     same torch version counter, i.e. not written through torch since -- was complete when the call that first saw it
+#     began; if that holds for every input, the side stream waits for the event recorded then, not for the caller stream's
+#     tail: forward(j+1)'s front end runs beside backward(j).  A new tensor, a bumped version counter (optimizer step, any
+#     in-place op), a tensor without a counter (inference mode): the side stream waits for the caller's stream as it is
+#     now -- exactly the unoverlapped order.
+# Tensors are remembered by weak reference (no lifetime is extended; a recycled address can not impersonate an old tensor).
+# What the version counter does not see -- `t.data.copy_(...)`, a foreign kernel writing through `data_ptr()` -- is not seen here
+# either: autograd's own in-place checks have the same blind spot.  GSR_OVERLAP=0 / set_overlap(False) restores plain
+# in-stream execution.  All outputs and arenas are allocated on the side stream and handed to the caller's stream with
+# record_stream, so torch's caching allocator never recycles them under a kernel that still runs.
+import weakref as _weakref
+
+_OVERLAP_ON = os.environ.get("GSR_OVERLAP", "1") != "0"
+_OVERLAP_STREAMS = 3
+OVERLAP_MAX_VIEWS = 3
+_OVERLAP = {}            # (device index, caller stream) -> _OverlapState
+OVERLAP_STATS = dict(calls=0, overlapped=0)
+
+
+def set_overlap(on):
+    """Switch the device-side overlap of consecutive forward calls on or off (off: every kernel on the caller's stream)."""
+    global _OVERLAP_ON
+    _OVERLAP_ON = bool(on)
+    if not on:
+        _OVERLAP.clear()
+
+
+class _OverlapState:
+    def __init__(self, device):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(_OVERLAP_STREAMS)]
+        self.turn = 0
+        self.seen = {}       # id(tensor) -> (weakref, version, event, sequence number)
+        self.seq = 0
+
+    def input_event(self, tensors, cur):
+        """The event the side stream has to wait for: the newest `first seen` event when every input is a known, unmodified
+        tensor, else an event recorded on the caller's stream now (under which the unknown inputs are registered)."""
+        self.seq += 1
+        newest, missing = None, []
+        for t in tensors:
+            try:
+                ver = t._version
+            except RuntimeError:      # inference tensor: no version counter, never assumed unchanged
+                return self._now(cur, []), False
+            rec = self.seen.get(id(t))
+            if rec is not None and rec[0]() is t and rec[1] == ver:
+                if newest is None or rec[3] > newest[3]:
+                    newest = rec
+            else:
+                missing.append((t, ver))
+        if missing or newest is None:
+            return self._now(cur, missing), False
+        return newest[2], True
+
+    def _now(self, cur, missing):
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        if len(self.seen) > 512:
+            self.seen = {k: r for k, r in self.seen.items() if r[0]() is not None}
+            if len(self.seen) > 512:
+                self.seen.clear()
+        for t, ver in missing:
+            self.seen[id(t)] = (_weakref.ref(t), ver, ev, self.seq)
+        return ev
+
+    def next_stream(self):
+        self.turn = (self.turn + 1) % len(self.streams)
+        return self.streams[self.turn]
+
+
+class _OnSideStream:
+    """Context of one forward call: inside, torch's current stream is a side stream that waits only for the call's inputs;
+    leaving it, the caller's stream is ordered behind the side stream and takes over the outputs handed to `give`."""
+
+    def __init__(self, device, tensors, enabled=True):
+        self.device, self.active, self.out = device, False, []
+        if not enabled or not _OVERLAP_ON or device.type != "cuda":
+            return
+        self.cur = torch.cuda.current_stream(device)
+        key = (device.index if device.index is not None else torch.cuda.current_device(), self.cur.cuda_stream)
+        st = _OVERLAP.get(key)
+        if st is None:
+            st = _OVERLAP[key] = _OverlapState(device)
+        live = [t for t in tensors if isinstance(t, torch.Tensor) and t.numel() != 0 and t.device.type == "cuda"]
+        ev, early = st.input_event(live, self.cur)
+        OVERLAP_STATS["calls"] += 1
+        OVERLAP_STATS["overlapped"] += int(early)
+        self.side = st.next_stream()
+        self.side.wait_event(ev)
+        self.active = True
+
+    def give(self, *tensors):
+        self.out += [t for t in tensors if isinstance(t, torch.Tensor) and t.numel() != 0]
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def __enter__(self):
+        if self.active:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self.cur.wait_event(done)
+            for t in self.out:
+                t.record_stream(self.cur)
+        return False
+
+
 def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
                               camposs, prefiltered, debug, need_backward=True, capacity=None, extra=None):
@@ -185,36 +307,44 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = means3D.device
     _require_hip(device)
-    viewmatrices = viewmatrices.reshape(-1, 4, 4)
-    projmatrices = projmatrices.reshape(-1, 4, 4)
-    camposs = camposs.reshape(-1, 3)
-    V = viewmatrices.shape[0]
-    if projmatrices.shape[0] != V or camposs.shape[0] != V or V < 1:
+    V = viewmatrices.numel() // 16
+    if viewmatrices.numel() != 16 * V or projmatrices.numel() != 16 * V or camposs.numel() != 3 * V or V < 1:
         raise RuntimeError("viewmatrices, projmatrices and camposs must describe the same number of views (>= 1)")
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     byte = dict(dtype=torch.uint8, device=device)
     nx = 0
+    xv = xs = xb = None
     if extra is not None:
         xv, xs, xb = extra
         nx = int(xv.shape[1]) if xv.dim() == 2 else -1
         if nx not in (4, 8) or xv.shape[0] != P:
             raise RuntimeError("extra channels must have shape (num_points, 4) or (num_points, 8)")
-        xv = _f32c(xv, device, "extra")
-        xb = _f32c(xb.reshape(-1), device, "bg_extra")
         if xb.numel() != nx or (xs is not None and tuple(xs.shape) != (V, nx)):
             raise RuntimeError("bg_extra must have nx entries and view_scale shape (V, nx)")
-        xs = None if xs is None else _f32c(xs, device, "extra_view_scale")
     if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
         e = torch.empty((0,), **byte)
         r0 = ([0] * V, torch.zeros((V, 3, H, W), dtype=torch.float32, device=device),
               torch.zeros((V, 0), dtype=torch.int32, device=device), e, e.clone(), e.clone())
         return r0 if extra is None else r0 + (torch.zeros((V, nx, H, W), dtype=torch.float32, device=device),)
-    out_extra = torch.empty((V, nx, H, W), dtype=torch.float32, device=device) if nx else None
-    # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
-    out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=device)
-    radii = torch.empty((V, P), dtype=torch.int32, device=device)
     key = _cap_key(device, P, W, H)
-    with torch.cuda.device(device):
+    # everything below -- layout conversions of the inputs, the allocation of outputs and arenas, every kernel -- happens on a side
+    # stream that waits for the inputs only (see _OnSideStream); the caller's stream takes the results over when the block ends
+    # (only calls of up to OVERLAP_MAX_VIEWS views: a 12-view batch has no tail for the next call's front end to hide behind, and
+    # running the two side by side costs 2.5 % on short bursts -- gpurun_out/r4k: 1 754 vs 1 711 frames/s at 20 frames per block)
+    ov = _OnSideStream(device, [background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrices, projmatrices,
+                                sh, camposs, xv, xs, xb], enabled=V <= OVERLAP_MAX_VIEWS)
+    with torch.cuda.device(device), ov:
+        viewmatrices = viewmatrices.reshape(-1, 4, 4)
+        projmatrices = projmatrices.reshape(-1, 4, 4)
+        camposs = camposs.reshape(-1, 3)
+        if nx:
+            xv = _f32c(xv, device, "extra")
+            xb = _f32c(xb.reshape(-1), device, "bg_extra")
+            xs = None if xs is None else _f32c(xs, device, "extra_view_scale")
+        out_extra = torch.empty((V, nx, H, W), dtype=torch.float32, device=device) if nx else None
+        # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
+        out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((V, P), dtype=torch.int32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
         p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                           viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, prefiltered, debug,
@@ -253,6 +383,7 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
                 binning = torch.empty((V * lib.gsr_binning_bytes(need),), **byte)
                 rc = submit(binning, 1)
             _check(rc)
+        ov.give(out_color, radii, geom, binning, img, out_extra)
     del keep
     counts = [int(c) for c in counts]
     _note_counts(key, counts)

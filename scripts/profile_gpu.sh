@@ -3,7 +3,7 @@
 # command (FETCH_SIZE, WRITE_SIZE, SQ counters: never combined with trace domains) and the FETCH_SIZE calibration probe.
 # Results under gpurun_out/prof_<tag>/; scripts/update_profiles.py <tag> copies what is judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 EXTRA=${2:-}            # extra bench.py arguments, e.g. "--views-per-call 12"
 MODE=${3:-full}         # "trace": kernel-trace stats only (no PMC passes)
 OUT=$PWD/gpurun_out/prof_$TAG
@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python $PWD/bench.py $EXTRA > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
-BENCH="python $PWD/bench.py --steps 12 --warmup 3 --repeats 2 --no-cpu-baseline --no-per-view --streams 1 $EXTRA"
+BENCH="python $PWD/bench.py --steps 24 --warmup 3 --repeats 2 --no-cpu-baseline --no-per-view --streams 1 $EXTRA"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1)
 if [ "$MODE" != "trace" ]; then
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/bench_pmc_fetch.log 2>&1)
@@ -34,6 +34,14 @@ TL="python $PWD/bench.py --steps 144 --warmup 12 --repeats 1 --no-cpu-baseline -
   echo; echo "== the same through the per-view call (GaussianRasterizer.forward + backward per view) =="; python $PWD/scripts/timeline.py $OUT/tl1 0.4 1; } > $OUT/timeline.txt 2>&1
 cat $OUT/timeline.txt
 find $OUT/tl12 $OUT/tl1 -name "*.csv" -size +1M -delete
+# secondary lines: configs[1] (200K voxelised, 1080p, forward only) and configs[4] (2M points, 4K, fwd+bwd, the
+# 8 views of a turn in one call on this one GPU)
+if [ "$MODE" != "trace" ]; then
+python $PWD/bench.py --config 1 --no-cpu-baseline --no-per-view > $OUT/bench_config1.json 2> $OUT/bench_config1.err
+python $PWD/bench.py --config 4 --steps 16 --warmup 8 --no-cpu-baseline --no-per-view > $OUT/bench_config4.json 2> $OUT/bench_config4.err
+python $PWD/bench.py --config 3 --steps 16 --warmup 8 --no-cpu-baseline --no-per-view > $OUT/bench_config3.json 2> $OUT/bench_config3.err
+tail -c 300 $OUT/bench_config1.err $OUT/bench_config4.err $OUT/bench_config3.err
+fi
 python $PWD/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt
 # keep the merge small: drop the raw per-dispatch traces, keep stats + counter CSVs

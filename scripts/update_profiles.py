@@ -6,7 +6,7 @@ usage: python scripts/update_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -64,8 +64,23 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
         k = short(r["Name"])
         if k.startswith("k_"):
             avg_us[k] = round(float(r["AverageNs"]) / 1e3, 3)
+# the shader clock the profiled (kernel-trace) run sustained: its own bench line, printed under rocprofv3
+prof_clk = None
+try:
+    tl = [l for l in open(os.path.join(src, "bench_trace.log")).read().splitlines() if l.startswith("{")]
+    if tl:
+        prof_clk = (json.loads(tl[-1]).get("sclk_mhz") or {}).get("stage_pass")
+except OSError:
+    pass
+for name in ("bench_config1", "bench_config3", "bench_config4"):
+    f = os.path.join(src, name + ".json")
+    if os.path.exists(f):
+        ls = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        if ls:
+            json.dump(json.loads(ls[-1]), open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w"), indent=1)
 out = {
     "key": key,
+    "sclk_mhz": prof_clk,
     "source": "profiles/%s_bench_rocprofv3_summary.txt: rocprofv3 kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes of "
               "`bench.py --streams 1` and the bench line profiles/%s_bench_line.json, all in one gpurun lease" % (tag, tag),
     "formula": "(fetch_factor x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch; fetch_factor from profiles/%s_fetch_calibration.txt "
@@ -99,6 +114,11 @@ if rf:
         rf["frac_profile"] = round(rf["algorithmic_bytes"] / (avg_us[kn] * 1e-6) / 1e9 / rf["peak"], 5)
         rel = rf["avg_ms"] / (avg_us[kn] / 1e3)
         rf["live_vs_profile"] = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
+        lclk = (bench.get("sclk_mhz") or {}).get("stage_pass")
+        if prof_clk and lclk:
+            reln = rel * lclk / prof_clk
+            rf["live_vs_profile"].update({"sclk_mhz_live": lclk, "sclk_mhz_profile": prof_clk, "ratio_clock_normalised": round(reln, 3),
+                                          "agree_within_10pct_clock_normalised": bool(abs(reln - 1.0) <= 0.10)})
     vi = out["valu_wave_instructions_per_launch"].get(kn)
     if vi:
         rate = vi / (rf["avg_ms"] * 1e-3)

@@ -202,3 +202,61 @@ def test_inference_geometry_arena_is_smaller_and_enough(gpu_device):
     c_bwd, col_bwd, rad_bwd, geom_bwd, *_ = N.rasterize_gaussians_batch(*args, need_backward=True)
     assert geom_inf.numel() == 3 * N.lib.gsr_geom_bytes_inference(P) and geom_bwd.numel() == 3 * N.lib.gsr_geom_bytes(P)
     assert c_inf == c_bwd and torch.equal(col_inf, col_bwd) and torch.equal(rad_inf, rad_bwd)
+
+
+def test_consecutive_per_view_calls_overlap_only_when_the_inputs_are_provably_unchanged(gpu_device):
+    """The library starts forward(j+1) beside backward(j) when every input is a tensor object it has seen before with an
+    unchanged version counter (_native._OnSideStream).  (1) Steady state of a per-view training loop: calls overlap and give
+    the gradients of the in-order run.  (2) An in-place update between two calls (an optimizer step) bumps the version
+    counter: the next call waits for the caller's stream and renders the UPDATED cloud.  (3) Fresh tensors every call
+    (matrices rebuilt on the device, like the reference's caller): never overlapped, same images.  (4) Switched off: every
+    kernel on the caller's stream again."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _native as N
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=4)
+
+    def loop(L, sl, n):
+        imgs = []
+        for k in range(n):
+            img, _ = GaussianRasterizer(sl[k % len(sl)])(**L)
+            (img * G).sum().backward()
+            imgs.append(img.detach().clone())
+        torch.cuda.synchronize()
+        return imgs
+
+    N.set_overlap(False)
+    L0 = leaves()
+    want = loop(L0, settings, 8)
+    g_want = {k: v.grad.clone() for k, v in L0.items()}
+    N.set_overlap(True)
+    N.OVERLAP_STATS.update(calls=0, overlapped=0)
+    L1 = leaves()
+    got = loop(L1, settings, 8)
+    assert N.OVERLAP_STATS["calls"] == 8 and N.OVERLAP_STATS["overlapped"] >= 3, N.OVERLAP_STATS   # second turn of the 4 views
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    for k in L1:
+        scale = float(g_want[k].abs().max()) + 1e-30
+        assert float((L1[k].grad - g_want[k]).abs().max()) <= 2e-5 * scale, k
+    # (2) an in-place step between calls is seen
+    N.OVERLAP_STATS.update(calls=0, overlapped=0)
+    with torch.no_grad():
+        L1["means3D"].add_(0.01)
+    img_moved, _ = GaussianRasterizer(settings[0])(**L1)
+    assert N.OVERLAP_STATS["overlapped"] == 0
+    L2 = leaves()
+    with torch.no_grad():
+        L2["means3D"].add_(0.01)
+    N.set_overlap(False)
+    img_ref, _ = GaussianRasterizer(settings[0])(**L2)
+    assert torch.equal(img_moved, img_ref) and not torch.equal(img_moved, want[0])
+    # (3) fresh matrices every call
+    N.set_overlap(True)
+    N.OVERLAP_STATS.update(calls=0, overlapped=0)
+    with torch.no_grad():
+        for k in range(6):
+            s = settings[k % 4]
+            s2 = s._replace(viewmatrix=s.viewmatrix * 1.0, projmatrix=s.projmatrix * 1.0, campos=s.campos * 1.0)
+            img, _ = GaussianRasterizer(s2)(**L0)
+            assert torch.equal(img, want[k % 4])
+    assert N.OVERLAP_STATS["overlapped"] == 0 and N.OVERLAP_STATS["calls"] == 6
