@@ -129,10 +129,11 @@ static int landing(HostLanding** out)
     if (!h.pinned) {
         if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&h.mapped, h.pinned, 0) != hipSuccess ||
-            // the event only has to say "the emission kernel has finished": the counters it waits for are stored to fine-grained
-            // (coherent, uncached) host memory and fenced by the kernel itself (__threadfence_system), so the record needs no
-            // system-scope release of the L2s in the middle of the frame
-            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+            // (hipEventDisableSystemFence on this event was tried -- the counters live in coherent host memory and the kernel fences
+            // them itself, so the record would not need the system-scope release of the L2s -- and cost the per-view path a fifth of
+            // its rate, 1 363 -> 1 050-1 130 frames/s, gpurun_out/r4m: waiting for such an event does not return when the emission
+            // kernel ends but when the stream drains, and the host stops running ahead of the device)
+            hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
             h.pinned = nullptr;
             return fail(GSR_ERR_HIP, "[gsr] pinned host buffer: %s", hipGetErrorString(hipGetLastError()));
         }

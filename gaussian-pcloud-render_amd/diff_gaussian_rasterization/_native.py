@@ -195,8 +195,15 @@ def reset_capacity_hints():
 # record_stream, so torch's caching allocator never recycles them under a kernel that still runs.
 import weakref as _weakref
 
+# Each side stream wants a hardware queue of its own (the ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES queues, default 4,
+# and streams that share a queue serialise); the variable is only read when HIP starts, so it can only be defaulted here if the
+# process has not touched the GPU yet.
+if not torch.cuda.is_initialized():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _OVERLAP_ON = os.environ.get("GSR_OVERLAP", "1") != "0"
-_OVERLAP_STREAMS = 3
+_OVERLAP_STREAMS = int(os.environ.get("GSR_OVERLAP_STREAMS", "3"))
+_OVERLAP_PRIORITY = int(os.environ.get("GSR_OVERLAP_PRIORITY", "-1"))    # -1: side streams above the caller's stream
 OVERLAP_MAX_VIEWS = 3
 _OVERLAP = {}            # (device index, caller stream) -> _OverlapState
 OVERLAP_STATS = dict(calls=0, overlapped=0)
@@ -205,14 +212,20 @@ OVERLAP_STATS = dict(calls=0, overlapped=0)
 def set_overlap(on):
     """Switch the device-side overlap of consecutive forward calls on or off (off: every kernel on the caller's stream)."""
     global _OVERLAP_ON
-    _OVERLAP_ON = bool(on)
-    if not on:
-        _OVERLAP.clear()
+    _OVERLAP_ON = bool(on)      # (the side streams are kept: the runtime maps streams to hardware queues in creation order, and a
+                                # later set of streams may land on the caller's queue -- 1 150 instead of 1 290 frames/s,
+                                # scripts/debug/overlap_warm.py)
 
 
 class _OverlapState:
-    def __init__(self, device):
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(_OVERLAP_STREAMS)]
+    def __init__(self, device, cur):
+        # side streams above the caller's priority: a view's front end is short and on the critical path of the next frame, the
+        # previous view's backward is not.  What the overlap is worth depends on which hardware queues / dispatch pipes the
+        # runtime binds these streams to at their first launch, which a process can neither see nor choose: 1 250-1 360 frames/s
+        # in most processes, 1 010-1 060 in some (in-order: 985), stable for the life of a process (gpurun_out/r4q*).  Choosing
+        # streams with a concurrency test of small spin kernels made it WORSE (1 000-1 140 in every process: the binding seems
+        # to follow what is in flight at the first launch), so the streams are taken as they come.
+        self.streams = [torch.cuda.Stream(device=device, priority=_OVERLAP_PRIORITY) for _ in range(_OVERLAP_STREAMS)]
         self.turn = 0
         self.seen = {}       # id(tensor) -> (weakref, version, event, sequence number)
         self.seq = 0
@@ -265,7 +278,7 @@ class _OnSideStream:
         key = (device.index if device.index is not None else torch.cuda.current_device(), self.cur.cuda_stream)
         st = _OVERLAP.get(key)
         if st is None:
-            st = _OVERLAP[key] = _OverlapState(device)
+            st = _OVERLAP[key] = _OverlapState(device, self.cur)
         live = [t for t in tensors if isinstance(t, torch.Tensor) and t.numel() != 0 and t.device.type == "cuda"]
         ev, early = st.input_event(live, self.cur)
         OVERLAP_STATS["calls"] += 1
