@@ -76,7 +76,7 @@ struct ProfTables {
         return (int)used++;
     }
 };
-static std::atomic<bool> g_prof_on{false};
+static std::atomic<int> g_prof_on{0};    // 0 off, 1 every stage, 2 the two render kernels only (cheap enough for a timed region)
 static std::mutex g_prof_mu;
 static std::map<hipStream_t, ProfTables> g_prof;   // guarded by g_prof_mu
 
@@ -84,8 +84,10 @@ struct ProfScope {
     hipStream_t s;
     bool on;
     ProfEntry e;
-    ProfScope(const char* name, hipStream_t stream) : s(stream), on(g_prof_on)
+    ProfScope(const char* name, hipStream_t stream) : s(stream), on(false)
     {
+        const int mode = g_prof_on;
+        on = mode == 1 || (mode == 2 && strncmp(name, "render_", 7) == 0);
         if (!on) return;
         e.name = name;
         hipEvent_t ea;
@@ -622,7 +624,7 @@ int gsr_wall_clock_khz(void)
 void gsr_set_profiling(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_on = on < 0 ? 0 : on > 2 ? 1 : on;
     for (auto& kv : g_prof) { kv.second.rec.clear(); kv.second.used = 0; }
 }
 

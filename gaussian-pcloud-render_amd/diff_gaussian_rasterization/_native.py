@@ -601,7 +601,8 @@ def selftest(device):
 
 
 def set_profiling(on):
-    lib.gsr_set_profiling(int(bool(on)))
+    """False / 0: off; True / 1: hipEvents around every stage; 2: around the two render kernels only"""
+    lib.gsr_set_profiling(int(on))
 
 
 def get_profile():

@@ -191,7 +191,8 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
 
 /* Per-stage timing of the calls made since gsr_set_profiling(1) (ms, hipEvents on each call's launch stream; the switch is
  * process wide, the records are kept per stream and returned stream by stream).  names/ms hold up to `cap` entries;
- * returns the count and resets the records. */
+ * returns the count and resets the records.  gsr_set_profiling(2) times only the two render kernels (one event pair per
+ * forward and per backward: cheap enough to leave on inside a timed region); 0 switches it off. */
 void gsr_set_profiling(int on);
 int gsr_get_profile(const char** names, float* ms, int cap);
 

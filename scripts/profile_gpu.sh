@@ -27,11 +27,13 @@ python $PWD/scripts/probe/fetch_calib_report.py $OUT/calib > $OUT/fetch_calibrat
 cat $OUT/fetch_calibration.txt
 fi
 # host-side audit: GPU idle time, copies and blocking API calls per rasterizer call (single stream, no stage events)
-TL="python $PWD/bench.py --steps 144 --warmup 12 --repeats 1 --no-cpu-baseline --no-per-view --streams 1 --no-stage-events $EXTRA"
+# (one long timed block; the untimed blocks before it -- priming, instrumentation warm-up, the block behind the garbage collection --
+# each end in a synchronize, so the audited window is cut from the last quarter of the trace: inside the timed block)
+TL="python $PWD/bench.py --steps 480 --warmup 12 --repeats 1 --warmup-seconds 0 --no-cpu-baseline --no-per-view --streams 1 --no-stage-events $EXTRA"
 (cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --hip-trace --output-format csv -d $OUT/tl12 -o tl -- $TL > $OUT/tl12.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace --hip-trace --output-format csv -d $OUT/tl1 -o tl -- $TL --views-per-call 1 > $OUT/tl1.log 2>&1)
-{ echo "== bench.py --streams 1 --no-stage-events, 12 views per rasterize_views call =="; python $PWD/scripts/timeline.py $OUT/tl12 0.4 12;
-  echo; echo "== the same through the per-view call (GaussianRasterizer.forward + backward per view) =="; python $PWD/scripts/timeline.py $OUT/tl1 0.4 1; } > $OUT/timeline.txt 2>&1
+{ echo "== bench.py --streams 1 --no-stage-events, 12 views per rasterize_views call =="; python $PWD/scripts/timeline.py $OUT/tl12 0.74 12;
+  echo; echo "== the same through the per-view call (GaussianRasterizer.forward + backward per view) =="; python $PWD/scripts/timeline.py $OUT/tl1 0.74 1; } > $OUT/timeline.txt 2>&1
 cat $OUT/timeline.txt
 find $OUT/tl12 $OUT/tl1 -name "*.csv" -size +1M -delete
 # secondary lines: configs[1] (200K voxelised, 1080p, forward only) and configs[4] (2M points, 4K, fwd+bwd, the
