@@ -260,3 +260,73 @@ def test_consecutive_per_view_calls_overlap_only_when_the_inputs_are_provably_un
             img, _ = GaussianRasterizer(s2)(**L0)
             assert torch.equal(img, want[k % 4])
     assert N.OVERLAP_STATS["overlapped"] == 0 and N.OVERLAP_STATS["calls"] == 6
+
+
+def test_overlap_of_consecutive_calls_survives_a_random_training_script(gpu_device):
+    """A scripted random mix of what a caller can do between two per-view calls -- optimizer-like in-place steps, a parameter
+    REPLACED by a new tensor, forward-only calls, calls under another current stream, retain_graph backwards, freed results --
+    gives bit-identical images and (to atomic-order noise) identical accumulated gradients with the library's overlap of
+    consecutive calls on and off."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _native as N
+    dev = gpu_device
+    settings, leaves, G = _setup(dev, n_views=5, P=9000, W=176, H=144)
+    other = torch.cuda.Stream(device=dev)
+
+    def script(seed):
+        rng = np.random.default_rng(seed)
+        L = leaves()
+        sums, keep = [], []
+        for step in range(70):
+            v = int(rng.integers(0, len(settings)))
+            what = rng.random()
+            if what < 0.15:                      # an optimizer step on a random parameter (in place, under no_grad)
+                k = ["means3D", "opacities", "scales", "shs"][int(rng.integers(0, 4))]
+                with torch.no_grad():
+                    L[k].add_(1e-3 * torch.from_numpy(rng.standard_normal(tuple(L[k].shape)).astype(np.float32)).to(dev))
+            elif what < 0.22:                    # a parameter replaced by a NEW tensor (densification does this)
+                L["rotations"] = (L["rotations"].detach() * 1.0).requires_grad_(True)
+            ctx = torch.cuda.stream(other) if rng.random() < 0.2 else _Null()
+            if isinstance(ctx, _Null):
+                pass
+            else:
+                other.wait_stream(torch.cuda.current_stream(dev))
+            with ctx:
+                if rng.random() < 0.25:
+                    with torch.no_grad():
+                        img, _ = GaussianRasterizer(settings[v])(**L)
+                else:
+                    img, _ = GaussianRasterizer(settings[v])(**L)
+                    loss = (img * G).sum()
+                    if rng.random() < 0.2:
+                        loss.backward(retain_graph=True)
+                    loss.backward()
+                sums.append(img.detach().clone())
+                if rng.random() < 0.3:
+                    keep.append(img)             # some results stay alive, most are freed at once
+            if not isinstance(ctx, _Null):
+                torch.cuda.current_stream(dev).wait_stream(other)
+        torch.cuda.synchronize()
+        return sums, {k: (None if t.grad is None else t.grad.clone()) for k, t in L.items()}
+
+    class _Null:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    N.set_overlap(False)
+    want, gw = script(11)
+    N.set_overlap(True)
+    N.OVERLAP_STATS.update(calls=0, overlapped=0)
+    got, gg = script(11)
+    assert N.OVERLAP_STATS["overlapped"] > 10, N.OVERLAP_STATS
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), "step %d" % i
+    for k in gw:
+        if gw[k] is None:
+            assert gg[k] is None
+            continue
+        scale = float(gw[k].abs().max()) + 1e-30
+        assert float((gg[k] - gw[k]).abs().max()) <= 1e-4 * scale, k
