@@ -261,9 +261,11 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         {
             ProfScope ps("depth_sort", L.stream);
             SortJob job{{B.g.dkey[0], B.g.dkey[1]}, {B.g.dval[0], B.g.dval[1]}, B.g.hist, B.g.totals, B.g_stride, nullptr, 0, p->P, V};
+            job.blk_minmax = B.g.blk_minmax;
+            job.sortctl = B.g.sortctl;
             int res = 0;
             if (int e = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 32, &res)) return e;
-            // 4 passes: the ids in depth order are back in buffer 0
+            // up to 4 passes (B.g.sortctl says how many did something): the ids in depth order are in dval[passes & 1]
         }
     }
     // the emission kernel leaves the counters of every view in mapped host memory; the event behind it is waited for only
@@ -506,6 +508,11 @@ __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const
     case GSR_Q_POINT_LIST_KEYS:
         ((uint64_t*)dst)[i] = ((uint64_t)(key16 ? (uint32_t)((const uint16_t*)k)[i] : k[i]) << 32) | (uint64_t)__float_as_uint(sp[v[i]].q2.y);
         break;
+    case GSR_Q_DEPTH_SORT: {
+        uint32_t* o = (uint32_t*)dst;   // k = the view's sortctl words
+        if (i == 0) { o[0] = k[SORTCTL_BASE]; o[1] = k[SORTCTL_BITS]; o[2] = depth_sort_passes(k[SORTCTL_BITS]); o[3] = 0u; }
+        break;
+    }
     case GSR_Q_CLAMPED: {
         uint8_t* c = (uint8_t*)dst;
         c[3 * i] = clamped[i] & 1; c[3 * i + 1] = (clamped[i] >> 1) & 1; c[3 * i + 2] = (clamped[i] >> 2) & 1;
@@ -546,6 +553,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     case GSR_Q_FINAL_T: src = iv.final_T; bytes = (size_t)N * 4; break;
     case GSR_Q_N_CONTRIB: src = iv.n_contrib; bytes = (size_t)N * 4; break;
     case GSR_Q_TILE_NEED: src = iv.tile_need; bytes = (size_t)T * 4; break;
+    case GSR_Q_DEPTH_SORT: n = 1; bytes = 16; break;
     default: return fail(GSR_ERR_INVALID, "[gsr] query: unknown item %d", what);
     }
     if (dst_bytes < bytes) return fail(GSR_ERR_CAPACITY, "[gsr] query %d: destination too small", what);
@@ -553,8 +561,8 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     if (src) {
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query copy failed");
     } else {
-        hipLaunchKernelGGL(k_query, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, what, n, g.splat, g.clamped, b.key[res],
-                           (int)tile_keys16(T), b.val[res], dst);
+        hipLaunchKernelGGL(k_query, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, what, n, g.splat, g.clamped,
+                           what == GSR_Q_DEPTH_SORT ? (const uint32_t*)g.sortctl : (const uint32_t*)b.key[res], (int)tile_keys16(T), b.val[res], dst);
         if (hipGetLastError() != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query kernel failed");
     }
     return GSR_OK;

@@ -59,7 +59,8 @@ int debug_dup_times(unsigned long long* out8, int reset)
 struct DupArgs {
     int P;
     uint32_t gridx;
-    const uint32_t* order;           // ids in depth order
+    const uint32_t* order[2];        // ids in depth order: the depth sort's ping-pong buffers ...
+    const uint32_t* sortctl;         // ... and how many of its passes ran this frame (an odd count leaves the result in buffer 1)
     const Splat* splat;              // q3 = (rect.x, rect.y, tiles touched, -) as written by k_preprocess
     uint64_t* dup_status;            // [nblk] zeroed before the launch; pair count + 1 once a workgroup has published
     uint64_t* counters;
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     DUP_T(t1);
     DUP_ADD(0, t1 - t0);
     const uint32_t blk = s_ticket;
-    const uint32_t* order = at_view(a.order, a.g_stride, view);
+    const uint32_t npass = depth_sort_passes(at_view(a.sortctl, a.g_stride, view)[SORTCTL_BITS]);
+    const uint32_t* order = at_view((npass & 1u) ? a.order[1] : a.order[0], a.g_stride, view);
     const Splat* splat = at_view(a.splat, a.g_stride, view);
 
     // A wave owns DUP_G groups of 64 consecutive Gaussians (positions in depth order); the G gathers are independent and in
@@ -265,7 +267,9 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     DupArgs a;
     a.P = P;
     a.gridx = (uint32_t)gridx;
-    a.order = B.g.dval[0];
+    a.order[0] = B.g.dval[0];
+    a.order[1] = B.g.dval[1];
+    a.sortctl = B.g.sortctl;
     a.splat = B.g.splat;
     a.dup_status = B.g.dup_status;
     a.counters = B.g.counters;

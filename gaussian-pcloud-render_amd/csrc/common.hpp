@@ -91,6 +91,8 @@ struct GeomView {
     uint32_t* dval[2];        // [P] Gaussian ids, ping-pong; after 4 passes dval[0] = ids in depth order
     uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts (depth sort)
     uint32_t* totals;         // [RADIX]
+    uint32_t* blk_minmax;     // [2 * nblk(P)] smallest / largest depth key of a visible Gaussian per sort block (pass 0's histogram)
+    uint32_t* sortctl;        // [4] SORTCTL_*: which key bits the depth sort really has to look at this frame (sort.hip)
     uint64_t* dup_status;     // [ceil(P / DUP_THREADS) + 1] pair count + 1 of each emission workgroup, then the ticket counter
     uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
     char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
@@ -156,6 +158,8 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.dval[1], p);
     carve(cur, g.hist, RADIX * nblk);
     carve(cur, g.totals, (size_t)RADIX);
+    carve(cur, g.blk_minmax, 2 * nblk);
+    carve(cur, g.sortctl, (size_t)4);
     g.zero_begin = cur;
     carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS) + 1);   // + the ticket counter
     g.zero_bytes = (size_t)(cur - g.zero_begin);
@@ -266,7 +270,18 @@ struct SortJob {
     size_t n_stride;
     int64_t cap;
     int V;
+    // Depth sort only (else NULL): pass 0 also finds the smallest / largest key that is not CULLED_KEY, and the passes over key
+    // bits that no two such keys differ in leave at once (SORTCTL_*; the result's ping-pong buffer is then sortctl-dependent)
+    uint32_t* blk_minmax = nullptr;   // [2 * nblk_pad] per view
+    uint32_t* sortctl = nullptr;      // [4] per view
 };
+// sortctl words: keys are compared as (key - SORTCTL_BASE) on bits [0, SORTCTL_BITS); SORTCTL_BASE has its low 8 bits clear, so
+// pass 0 (which runs before the words exist) sees the same digit either way
+constexpr int SORTCTL_BASE = 0;
+constexpr int SORTCTL_BITS = 1;     // >= 8: passes whose shift is >= this many bits are skipped
+constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;   // depth key of a Gaussian that emits no pairs: its place in the order is immaterial
+// number of depth-sort passes a frame with SORTCTL_BITS = bits executes; ids in depth order end up in dval[passes & 1]
+__host__ __device__ inline uint32_t depth_sort_passes(uint32_t bits) { return (bits + RADIX_BITS - 1) / RADIX_BITS; }
 int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16 = false);
 inline bool tile_keys16(int T) { return T <= 65536; }
 // binning.hip

@@ -54,7 +54,18 @@ struct SortView {
     const uint64_t* n_dev;
     size_t n_stride;
     int64_t cap;
+    const uint32_t* ctl;   // sortctl of view 0 (depth sort, passes 1..3) or NULL
 };
+// The depth sort's later passes compare (key - base) and leave at once when their bits are above every difference between two
+// keys of visible Gaussians (wave-uniform: one scalar load).  Returns false when the pass has nothing to do.
+__device__ __forceinline__ bool pass_control(const SortView& sv, uint32_t view, int shift, uint32_t& base)
+{
+    base = 0u;
+    if (sv.ctl == nullptr) return true;
+    const uint32_t* c = at_view(sv.ctl, sv.stride, view);
+    base = c[SORTCTL_BASE];
+    return (uint32_t)shift < c[SORTCTL_BITS];
+}
 __device__ __forceinline__ int64_t view_count(const SortView& sv, uint32_t view)
 {
     if (sv.n_dev == nullptr) return sv.cap;
@@ -71,23 +82,31 @@ constexpr int HIST_GROUP = 16;
 
 template <typename KeyT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restrict__ keys, SortView sv, int shift,
-                                                           uint32_t mask, uint32_t* __restrict__ hist, int nblk_pad)
+                                                           uint32_t mask, uint32_t* __restrict__ hist, int nblk_pad,
+                                                           uint32_t* __restrict__ minmax)   // depth sort, pass 0: [2][nblk_pad], else NULL
 {
     const uint32_t view = blockIdx.y;
+    uint32_t kbase;
+    if (!pass_control(sv, view, shift, kbase)) return;
     const int64_t n = view_count(sv, view);
     keys = at_view(keys, sv.stride, view);
     hist = at_view(hist, sv.stride, view);
+    if (minmax) minmax = at_view(minmax, sv.stride, view);
     const uint32_t d = threadIdx.x;
     if ((int64_t)blockIdx.x * RS_TILE >= n) {   // past the end: this block's column of the count matrix is zero
         if (d <= mask) hist[(size_t)d * nblk_pad + blockIdx.x] = 0;
+        if (minmax && d == 0) { minmax[blockIdx.x] = 0xFFFFFFFFu; minmax[nblk_pad + blockIdx.x] = 0u; }
         return;
     }
     // HIST_COPIES private histograms (four per wave, by lane mod 4): same-digit keys of one wave instruction serialise in
     // the LDS atomic unit, the copies quarter those collisions
     constexpr int HIST_COPIES = 4 * RS_WAVES;
     __shared__ __attribute__((aligned(16))) uint32_t h[HIST_COPIES][RADIX];
+    __shared__ uint32_t s_min, s_max;
     for (int i = threadIdx.x; i < HIST_COPIES * RADIX / 4; i += RS_THREADS) reinterpret_cast<uint4*>(&h[0][0])[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; }
     __syncthreads();
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const uint32_t w = (threadIdx.x >> 6) * 4u + (threadIdx.x & 3u);
     if (sizeof(KeyT) == 2 && RS_ITEMS % 8 == 0 && base + RS_TILE <= n) {
@@ -107,10 +126,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; i++) {
             const int64_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&h[w][((uint32_t)keys[idx] >> shift) & mask], 1u);
+            if (idx < n) {
+                const uint32_t key = (uint32_t)keys[idx];
+                atomicAdd(&h[w][((key - kbase) >> shift) & mask], 1u);
+                if (key != CULLED_KEY) { kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+            }
         }
     }
+    if (minmax) {   // (uniform) smallest / largest key of a visible Gaussian in this block
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const uint32_t a = __shfl_xor(kmin, dd, 64), b = __shfl_xor(kmax, dd, 64);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_min, kmin); atomicMax(&s_max, kmax); }
+    }
     __syncthreads();
+    if (minmax && d == 0) { minmax[blockIdx.x] = s_min; minmax[nblk_pad + blockIdx.x] = s_max; }
     if (d <= mask) {
         uint32_t c = 0;
 #pragma unroll
@@ -120,12 +153,43 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
 }
 
 // ---- pass kernel 2: exclusive scan of each digit's row of workgroup counts -----------------------
+// Depth sort, pass 0: one more workgroup (blockIdx.x == nrows) reduces the per-block key extremes of the histogram kernel into
+// the view's sortctl words -- base = smallest key with its low 8 bits cleared, bits = position of the highest bit in which
+// (largest key - base) is set -- so that the passes above `bits` leave at once: depths within a factor of two of each other
+// differ in at most 24 bits (one binade = 2^23 codes), and the fourth pass of the 32-bit sort moves nothing.
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblk_pad,
-                                                       size_t stride)
+                                                       size_t stride, const uint32_t* __restrict__ ctl, int shift,
+                                                       const uint32_t* __restrict__ minmax, uint32_t* __restrict__ ctl_out,
+                                                       uint32_t nrows)
 {
+    __shared__ uint32_t tmp[4];
+    if (blockIdx.x == nrows) {
+        minmax = at_view(minmax, stride, blockIdx.y);
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (int b = threadIdx.x; b < nblk_pad; b += 256) {
+            const uint32_t a = minmax[b], c = minmax[nblk_pad + b];
+            kmin = a < kmin ? a : kmin;
+            kmax = c > kmax ? c : kmax;
+        }
+        __shared__ uint32_t s_min, s_max;
+        if (threadIdx.x == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; }
+        __syncthreads();
+        atomicMin(&s_min, kmin);
+        atomicMax(&s_max, kmax);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* c = at_view(ctl_out, stride, blockIdx.y);
+            const uint32_t base = s_min <= s_max ? (s_min & ~(uint32_t)(RADIX - 1)) : 0u;
+            const uint32_t span = s_min <= s_max ? s_max - base : 0u;      // no visible Gaussian: one pass, any order
+            const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+            c[SORTCTL_BASE] = base;
+            c[SORTCTL_BITS] = bits < (uint32_t)RADIX_BITS ? (uint32_t)RADIX_BITS : bits;
+        }
+        return;
+    }
+    if (ctl != nullptr && (uint32_t)shift >= at_view(ctl, stride, blockIdx.y)[SORTCTL_BITS]) return;
     hist = at_view(hist, stride, blockIdx.y);
     totals = at_view(totals, stride, blockIdx.y);
-    __shared__ uint32_t tmp[4];
     uint32_t* row = hist + (size_t)blockIdx.x * nblk_pad;
     uint32_t carry = 0;
     for (int b0 = 0; b0 < nblk_pad; b0 += 256) {
@@ -177,6 +241,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
                                                               const uint32_t* __restrict__ totals, int nblk_pad)
 {
     const uint32_t view = blockIdx.y;
+    uint32_t kbase;
+    if (!pass_control(sv, view, shift, kbase)) return;
     const int64_t n = view_count(sv, view);
     // Workgroup -> sort block: the HIST_GROUP blocks whose counters share a 64-B line of the count matrix run on ONE XCD
     // (workgroup w runs on XCD w % 8), so the line is fetched into that L2 once instead of by sixteen different L2s.
@@ -212,9 +278,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     {
         const KeyT* kp = keys_in + seg_base + lane;
         const uint32_t* vp = vals_in ? vals_in + seg_base + lane : nullptr;
+        // keys are ranked (and staged) as key - kbase; kbase goes back on when they are written (kbase = 0 but in the depth sort)
         if (full) {
 #pragma unroll
-            for (int j = 0; j < RS_ITEMS; j++) k[j] = (uint32_t)kp[j * 64];
+            for (int j = 0; j < RS_ITEMS; j++) k[j] = (uint32_t)kp[j * 64] - kbase;
             if (vp) {
 #pragma unroll
                 for (int j = 0; j < RS_ITEMS; j++) v[j] = vp[j * 64];
@@ -227,7 +294,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             for (int j = 0; j < RS_ITEMS; j++) {
                 const int64_t idx = seg_base + j * 64 + lane;
                 const bool ok = idx < n;
-                k[j] = ok ? (uint32_t)kp[j * 64] : 0xFFFFFFFFu;
+                k[j] = ok ? (uint32_t)kp[j * 64] - kbase : 0xFFFFFFFFu;
                 v[j] = ok ? (vp ? vp[j * 64] : (uint32_t)idx) : 0u;
             }
         }
@@ -310,7 +377,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             const uint32_t key = s_key[p];
             const uint32_t d = (key >> shift) & mask;
             const size_t g = (size_t)global_base[d] + (p - local_base[d]);
-            keys_out[g] = (KeyT)key;
+            keys_out[g] = (KeyT)(key + kbase);
             vals_out[g] = s_val[p];
         }
     }
@@ -327,7 +394,7 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
     if (job.cap > 0 && job.V > 0) {
         const int nblk = (int)div_up(job.cap, RS_TILE);
         const int nblk_pad = sort_hist_stride(job.cap);
-        const SortView sv{job.stride, job.n_dev, job.n_stride, job.cap};
+        SortView sv{job.stride, job.n_dev, job.n_stride, job.cap, nullptr};
         const dim3 grid_hist(nblk_pad, job.V);
         const dim3 grid((unsigned)div_up(nblk, 8 * HIST_GROUP) * 8 * HIST_GROUP, job.V);   // see the workgroup -> block map
         bool first = true;
@@ -336,14 +403,19 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
         for (int pass = 0; pass < npass; pass++) {
             const int bits = (end_bit - shift + (npass - pass) - 1) / (npass - pass);   // even split, wider digits first
             const uint32_t mask = (1u << bits) - 1u;
+            // depth sort: pass 0 produces the control words, the later passes obey them
+            const bool make_ctl = job.sortctl != nullptr && pass == 0;
+            sv.ctl = (job.sortctl != nullptr && pass > 0) ? job.sortctl : nullptr;
+            uint32_t* minmax = make_ctl ? job.blk_minmax : nullptr;
             if (key16)
                 hipLaunchKernelGGL(k_radix_hist<uint16_t>, grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint16_t*)job.key[cur], sv,
-                                   shift, mask, job.hist, nblk_pad);
+                                   shift, mask, job.hist, nblk_pad, minmax);
             else
                 hipLaunchKernelGGL(k_radix_hist<uint32_t>, grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint32_t*)job.key[cur], sv,
-                                   shift, mask, job.hist, nblk_pad);
+                                   shift, mask, job.hist, nblk_pad, minmax);
             if (int e = check_launch(L, "radix_hist")) return e;
-            hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1u, job.V), dim3(256), 0, L.stream, job.hist, job.totals, nblk_pad, job.stride);
+            hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1u + (make_ctl ? 1u : 0u), job.V), dim3(256), 0, L.stream, job.hist,
+                               job.totals, nblk_pad, job.stride, sv.ctl, shift, (const uint32_t*)minmax, job.sortctl, mask + 1u);
             if (int e = check_launch(L, "radix_rowscan")) return e;
             const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)job.val[cur];
 #define GSR_SCATTER(B)                                                                                                        \

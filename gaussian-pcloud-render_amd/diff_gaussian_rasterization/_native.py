@@ -38,7 +38,7 @@ SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr
 GSR_RETRY = 1
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
-         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12)
+         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, DEPTH_SORT=13)
 
 
 def _load():
@@ -522,6 +522,7 @@ _QSPEC = {
     "POINT_LIST_KEYS": (torch.int64, lambda P, R, T, N: (R,)), "RANGES": (torch.int32, lambda P, R, T, N: (T, 2)),
     "FINAL_T": (torch.float32, lambda P, R, T, N: (N,)), "N_CONTRIB": (torch.int32, lambda P, R, T, N: (N,)),
     "CLAMPED": (torch.uint8, lambda P, R, T, N: (P, 3)), "TILE_NEED": (torch.int32, lambda P, R, T, N: (T,)),
+    "DEPTH_SORT": (torch.int32, lambda P, R, T, N: (4,)),
 }
 
 

@@ -186,6 +186,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 #define GSR_Q_N_CONTRIB 10     /* uint32 [H*W]                                                              */
 #define GSR_Q_TILE_NEED 12     /* uint32 [T]   list entries the tile's render actually walked (roofline model)    */
 #define GSR_Q_CLAMPED 11       /* uint8  [P,3]                                                              */
+#define GSR_Q_DEPTH_SORT 13    /* uint32 [4]   depth sort of the frame: key base, key bits compared, passes run, -  */
 int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, size_t binning_bytes, const void* image,
               int64_t num_rendered, void* dst, size_t dst_bytes, gsr_stream_t stream);
 

@@ -50,6 +50,21 @@ def _check_geom_floats_exact(p, o, tag, has_sh=True):
         assert a.tobytes() == b.tobytes(), "%s: %s differs (max ulp %d)" % (tag, k, util.ulp_diff(a, b).max())
 
 
+@pytest.mark.parametrize("npass", [1, 2, 3, 4])
+def test_depth_sort_runs_only_the_passes_the_keys_need(npass, oracle, gpu_device):
+    """The depth sort looks at the key bits in which two visible Gaussians' depth keys can differ (sort.hip, SORTCTL_*): scenes
+    whose keys span 8 / 16 / 24 / 32 bits run 1 / 2 / 3 / 4 passes, and the sorted lists are the oracle's either way (culled
+    Gaussians, key 0xFFFFFFFF, neither widen the span nor appear in a list)."""
+    s = build_scene("depth_span_%d" % npass)
+    o = oracle.forward(s)
+    p, _ = run_product(s, gpu_device)
+    base, bits, passes = (int(x) for x in p["depth_sort"][:3])
+    vis_keys = o["depths"][o["radii"] > 0].view(np.uint32)
+    assert passes == npass, "depth keys %#x..%#x: %d passes (base %#x, %d bits)" % (vis_keys.min(), vis_keys.max(), passes, base, bits)
+    assert base % 256 == 0 and base <= vis_keys.min() and int(vis_keys.max()) - base < (1 << bits)
+    _check_integers(p, o, "depth_span_%d" % npass)
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_forward_vs_oracle(name, oracle, gpu_device):
     s = build_scene(name)

@@ -143,6 +143,26 @@ def build_scene(name):
                  opacities=rng.uniform(0.004, 0.0075, (P, 1)).astype(np.float32),   # alpha hovers around the 1/255 cut
                  shs=(0.6 * rng.standard_normal((P, 4, 3))).astype(np.float32), sh_degree=1)
         return scene_from(g, identity_camera(W, H), W, H, bg=(0.2, 0.3, 0.4))
+    if name.startswith("depth_span_"):   # depth keys that differ in 8 / 16 / 24 / 32 bits: the depth sort runs 1 / 2 / 3 / 4 passes
+        npass = int(name[-1])
+        W, H = 96, 64
+        rng = np.random.default_rng(40 + npass)
+        g = synth.random_scene(1800, W, H, seed=30 + npass, sh_degree=1)
+        P = g["means3D"].shape[0]
+        if npass == 4:
+            z = np.exp(rng.uniform(np.log(0.25), np.log(60.0), P)).astype(np.float32)       # eight binades
+        else:
+            # codes base .. base + span - 1 straddling the binade boundary at 2.0 (identity camera: view-space z = z);
+            # base is a multiple of 256, so the span is what the sort sees
+            span = {1: 200, 2: 60000, 3: 6000000}[npass]
+            base = (np.float32(2.0).view(np.uint32) - np.uint32(span // 2)) & np.uint32(0xFFFFFF00)
+            z = (base + rng.integers(0, span, P).astype(np.uint32)).view(np.float32)
+            z[:2] = np.array([base, base + np.uint32(span - 1)], np.uint32).view(np.float32)  # both ends present
+        g["means3D"][:, 0] *= z / g["means3D"][:, 2]      # keep the screen position
+        g["means3D"][:, 1] *= z / g["means3D"][:, 2]
+        g["means3D"][:, 2] = z
+        g["means3D"][5::9, 2] = -1.0                       # culled Gaussians (key 0xFFFFFFFF) do not count
+        return scene_from(g, identity_camera(W, H), W, H, bg=(0.3, 0.3, 0.3))
     if name == "one_gaussian":
         W, H = 33, 17
         g = dict(means3D=np.array([[0.05, -0.02, 1.5]], np.float32), scales=np.array([[0.2, 0.05, 0.1]], np.float32),
@@ -154,7 +174,8 @@ def build_scene(name):
 
 SCENES = ["random_aniso", "sh_deg0", "sh_deg1", "sh_deg2", "sh_deg3", "colors_precomp", "cov3d_precomp",
           "scale_modifier", "culled_mix", "all_culled", "voxel_ties", "opaque_early_stop", "capsule_circle",
-          "capsule_axis_view", "big_splats", "deep_stack", "one_gaussian"]
+          "capsule_axis_view", "big_splats", "deep_stack", "one_gaussian", "depth_span_1", "depth_span_2", "depth_span_3",
+          "depth_span_4"]
 
 
 def seeded_dL(scene, seed=123):
@@ -189,6 +210,7 @@ def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None, li
             keys=q("POINT_LIST_KEYS").view(np.uint64), ranges=q("RANGES").view(np.uint32),
             final_T=q("FINAL_T").reshape(H, W), n_contrib=q("N_CONTRIB").view(np.uint32).reshape(H, W),
         )
+        out["depth_sort"] = q("DEPTH_SORT").view(np.uint32)   # key base, key bits compared, passes run
         if nb:
             out["clamped"] = q("CLAMPED")
         out["visible"] = int((out["radii"] > 0).sum())
