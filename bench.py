@@ -69,7 +69,9 @@ def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes, views_per_cal
     views, and the backward's outputs ((40 + 12 K) V) are written once (summed over the views in registers).  The sort figures
     follow this library's own data flow (u32 depth keys and ids; tile keys are u16 for images of up to 65 536 tiles); the tile
     ranges are found by binary search (about 24 two-byte probes per tile), not by a pass over the keys, and the prefix sum of the
-    tile counts is part of the pair emission (no separate scan)."""
+    tile counts is part of the pair emission (no separate scan).  R here is the number of pairs IN THE LISTS (`list_pairs_avg` of
+    the line: the reference's num_rendered minus the pairs footprint clipping leaves out, include/gsr.h reference_lists); C_fwd /
+    C_bwd are the list entries the render kernels consume, counted in those lists."""
     b = {}
     kb = 2 if T <= 65536 else 4
     vpc = max(1, int(views_per_call))
@@ -554,7 +556,7 @@ def main():
     if rank == 0:
         # ---- workload statistics for the bytes model, averaged over the views rank 0 rendered
         used = sorted({view_of(warm + i, 0, world, n_views, shard) for i in range(args.steps * max(1, args.repeats))})
-        stats = dict(V=0.0, R=0.0, C_fwd=0.0, C_bwd=0.0)
+        stats = dict(V=0.0, R=0.0, L=0.0, C_fwd=0.0, C_bwd=0.0)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         with torch.no_grad():
             for c0 in range(0, len(used), VPC):
@@ -575,10 +577,11 @@ def main():
                     cb = ncp.view(ncp.shape[0] // 16, 16, ncp.shape[1] // 16, 16).amax(dim=(1, 3)).long().sum()
                     stats["V"] += float((radii[k] > 0).sum()) / len(used)
                     stats["R"] += float(R) / len(used)
+                    stats["L"] += float(_native.query("LIST_PAIRS", P, W, H, R, geom, binning, img, view=k, n_views=len(vs))[0]) / len(used)
                     stats["C_fwd"] += float(need.sum()) / len(used)
                     stats["C_bwd"] += float(cb) / len(used)
         tile_bits = int(T).bit_length()
-        bytes_per = algorithmic_bytes(P, stats["V"], stats["R"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
+        bytes_per = algorithmic_bytes(P, stats["V"], stats["L"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
                                       (tile_bits + 7) // 8, views_per_call=VPC)
         dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
         roofline = None
@@ -732,7 +735,11 @@ def main():
                 "baseline_config": cfg["what"],
                 "call_shape": {"views_per_call": VPC, "calls_in_flight": args.streams,
                                "entry_point": "rasterize_views" if VPC > 1 else "GaussianRasterizer.forward"},
-                "points": P, "num_rendered_avg": int(stats["R"]), "visible_avg": int(stats["V"]),
+                "points": P, "num_rendered_avg": int(stats["R"]), "list_pairs_avg": int(stats["L"]),
+                "list_pairs_note": "num_rendered = pairs of the reference's tile rectangles (reported bit-exact); list_pairs = pairs the "
+                                   "library emits and sorts: rectangles clipped to where alpha can reach 1/255 (gsr_params.reference_lists = 0, "
+                                   "the default; GSR_REFERENCE_LISTS=1 restores the reference's lists)",
+                "visible_avg": int(stats["V"]),
                 "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
             "roofline": roofline,
             "cpu_baseline": cpu,

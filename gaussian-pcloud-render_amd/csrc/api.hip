@@ -144,6 +144,9 @@ static int landing(HostLanding** out)
     return GSR_OK;
 }
 
+// pairs in the lists of the calling thread's last forward, per view (<= num_rendered: footprint clipping); gsr_last_list_pairs
+static thread_local std::vector<int64_t> t_list_pairs;
+
 // device->host read-backs the library has issued since it was loaded (one per forward call: the per-view counters)
 static std::atomic<long long> g_d2h_count{0};
 
@@ -312,8 +315,11 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     if (hipEventSynchronize(t_land.ev) != hipSuccess)
         return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
     bool retry = false;
+    t_list_pairs.assign((size_t)V, 0);
     for (int v = 0; v < V; v++) {
-        const uint64_t R = t_land.pinned[4 * v];
+        // R: pairs of the reference's tile rectangles (what the reference calls num_rendered); L: pairs in this library's
+        // lists (fewer when the rectangles are clipped to the splats' footprints) -- the arena has to hold L
+        const uint64_t R = t_land.pinned[4 * v + LAND_NUM_REFERENCE], Lp = t_land.pinned[4 * v + CNT_NUM_RENDERED];
         if (t_land.pinned[4 * v + CNT_STALL])
             return fail(GSR_ERR_HIP, "[gsr] pair emission: a workgroup's pair count never arrived (view %d)", v);
         if (p->prefiltered && t_land.pinned[4 * v + CNT_TRAP])
@@ -323,10 +329,11 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
             return fail(GSR_ERR_CAPACITY, "[gsr] num_rendered = %llu tile pairs does not fit the reference's int (scales too large?)",
                         (unsigned long long)R);
         num_rendered[v] = (int64_t)R;
-        if (mode != 2 && (int64_t)R > B.b.cap) retry = true;
+        t_list_pairs[(size_t)v] = (int64_t)Lp;
+        if (mode != 2 && (int64_t)Lp > B.b.cap) retry = true;
     }
     if (retry) {
-        fail(GSR_RETRY, "[gsr] binning arena holds %lld pairs per view, the frame needs more (see num_rendered): repeat with resume = 1",
+        fail(GSR_RETRY, "[gsr] binning arena holds %lld pairs per view, the frame needs more (num_rendered is enough; gsr_last_list_pairs is exact): repeat with resume = 1",
              (long long)B.b.cap);
         return GSR_RETRY;
     }
@@ -508,6 +515,11 @@ __global__ void k_query(int what, int64_t n, const Splat* __restrict__ sp, const
     case GSR_Q_POINT_LIST_KEYS:
         ((uint64_t*)dst)[i] = ((uint64_t)(key16 ? (uint32_t)((const uint16_t*)k)[i] : k[i]) << 32) | (uint64_t)__float_as_uint(sp[v[i]].q2.y);
         break;
+    case GSR_Q_LIST_PAIRS: {
+        const uint64_t* c = (const uint64_t*)k;   // k = the view's counters
+        if (i == 0) { ((uint64_t*)dst)[0] = c[CNT_NUM_RENDERED]; ((uint64_t*)dst)[1] = c[CNT_NUM_REFERENCE]; }
+        break;
+    }
     case GSR_Q_DEPTH_SORT: {
         uint32_t* o = (uint32_t*)dst;   // k = the view's sortctl words
         if (i == 0) { o[0] = k[SORTCTL_BASE]; o[1] = k[SORTCTL_BITS]; o[2] = depth_sort_passes(k[SORTCTL_BITS]); o[3] = 0u; }
@@ -533,7 +545,8 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     const GeomView g = geom_view(align256(const_cast<void*>(geom)), P);
     if (binning && binning_bytes < 512) return fail(GSR_ERR_CAPACITY, "[gsr] query: binning arena too small");
     const int64_t cap = binning ? bin_capacity_from_bytes(((binning_bytes - 256)) / 256 * 256) : 0;
-    if (binning && R > cap) return fail(GSR_ERR_CAPACITY, "[gsr] query: arena holds %lld pairs, R = %lld", (long long)cap, (long long)R);
+    if (binning && R > cap && (what == GSR_Q_POINT_LIST || what == GSR_Q_POINT_LIST_KEYS))
+        return fail(GSR_ERR_CAPACITY, "[gsr] query: arena holds %lld pairs, asked for %lld (the lists hold GSR_Q_LIST_PAIRS pairs)", (long long)cap, (long long)R);
     const BinView b = bin_view(align256(const_cast<void*>(binning)), cap > 0 ? cap : 1);
     const ImageView iv = image_view(align256(const_cast<void*>(image)), p->W, p->H);
     const int res = sorted_buffer(T);
@@ -554,6 +567,7 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
     case GSR_Q_N_CONTRIB: src = iv.n_contrib; bytes = (size_t)N * 4; break;
     case GSR_Q_TILE_NEED: src = iv.tile_need; bytes = (size_t)T * 4; break;
     case GSR_Q_DEPTH_SORT: n = 1; bytes = 16; break;
+    case GSR_Q_LIST_PAIRS: n = 1; bytes = 16; break;
     default: return fail(GSR_ERR_INVALID, "[gsr] query: unknown item %d", what);
     }
     if (dst_bytes < bytes) return fail(GSR_ERR_CAPACITY, "[gsr] query %d: destination too small", what);
@@ -562,7 +576,9 @@ int gsr_query(const gsr_params* p, int what, const void* geom, const void* binni
         if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query copy failed");
     } else {
         hipLaunchKernelGGL(k_query, dim3((unsigned)div_up(n, 256)), dim3(256), 0, s, what, n, g.splat, g.clamped,
-                           what == GSR_Q_DEPTH_SORT ? (const uint32_t*)g.sortctl : (const uint32_t*)b.key[res], (int)tile_keys16(T), b.val[res], dst);
+                           what == GSR_Q_DEPTH_SORT ? (const uint32_t*)g.sortctl
+                           : what == GSR_Q_LIST_PAIRS ? (const uint32_t*)g.counters : (const uint32_t*)b.key[res],
+                           (int)tile_keys16(T), b.val[res], dst);
         if (hipGetLastError() != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] query kernel failed");
     }
     return GSR_OK;
@@ -667,6 +683,13 @@ __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long lon
 #endif
 
 long long gsr_d2h_count(void) { return gsr::g_d2h_count.load(); }
+
+int gsr_last_list_pairs(int64_t* out, int V)
+{
+    if (!out || V < 0) return fail(GSR_ERR_INVALID, "[gsr] gsr_last_list_pairs: bad argument");
+    for (int v = 0; v < V; v++) out[v] = (size_t)v < gsr::t_list_pairs.size() ? gsr::t_list_pairs[(size_t)v] : 0;
+    return GSR_OK;
+}
 
 const char* gsr_last_error(void) { return gsr::g_err; }
 const char* gsr_version(void) { return "gsr-hip 0.2 (gfx950)"; }

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     __shared__ uint2 s_rect[4][64];
     __shared__ uint32_t s_flag[4][64];
     __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_ref[4];
     __shared__ uint64_t s_base;
     __shared__ uint32_t s_ticket;
     const uint32_t view = blockIdx.y;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     // once per DUP_G * 256 Gaussians.
     uint32_t cnt[DUP_G], id[DUP_G];
     uint2 rc[DUP_G];
+    uint64_t ref_cnt = 0;   // pairs of the reference's (unclipped) rectangles: only their total is needed (num_rendered)
     const int slot0 = (int)(blk * DUP_BLOCK + w * (64 * DUP_G) + lane);
 #pragma unroll
     for (int g = 0; g < DUP_G; g++) {
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
             const float4 q3 = splat[id[g]].q3;   // one 16-B gather: tile rectangle + tile count
             rc[g] = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
             cnt[g] = __float_as_uint(q3.z);
+            ref_cnt += __float_as_uint(q3.w);
         }
     }
     // ---- prefix sum: inside the wave (group after group), over the workgroup's waves, over the preceding workgroups ----
@@ -135,19 +138,27 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
         excl[g] = run + inc64 - cnt[g];
         run += (uint64_t)__shfl((unsigned long long)inc64, 63, 64);
     }
-    if (lane == 63) s_wave[w] = run;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ref_cnt += (uint64_t)__shfl_xor((unsigned long long)ref_cnt, d, 64);
+    if (lane == 63) { s_wave[w] = run; s_ref[w] = ref_cnt; }
     __syncthreads();
     uint64_t wave_base = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if ((uint32_t)i < w) wave_base += s_wave[i];
     const uint64_t block_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (threadIdx.x == 0) agent_store(&status[blk], block_total + 1);
+    const uint64_t block_ref = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3];
+    // One 64-bit status word carries both counts of the ticket's 1 024 Gaussians: pairs emitted + 1 in the low half, pairs of
+    // the reference's rectangles in the high half.  A count that does not fit its half saturates: the reference total then
+    // exceeds the int the reference keeps num_rendered in, which the host reports as an error before anything uses the lists.
+    const uint64_t sat = 0xFFFFFFFEull;
+    const uint64_t word = ((block_total < sat ? block_total : sat) + 1ull) | ((block_ref < 0xFFFFFFFFull ? block_ref : 0xFFFFFFFFull) << 32);
+    if (threadIdx.x == 0) agent_store(&status[blk], word);
     DUP_T(t2);
     DUP_ADD(1, t2 - t1);
     // look-back: every preceding workgroup's count (published as count + 1; 0 = not yet).  They were dispatched before
     // this one, so waiting for them cannot deadlock.
-    uint64_t part = 0;
+    uint64_t part = 0, part_ref = 0;
     // LB words per thread are requested back to back (one round trip to the fabric instead of LB); a word that has not been
     // published yet is polled afterwards.
     constexpr uint32_t LB = 4;
@@ -161,32 +172,41 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
 #pragma unroll
         for (uint32_t k = 0; k < LB; k++) {
             uint32_t spins = 0;
-            while (v[k] == 0) {
+            while ((uint32_t)v[k] == 0u) {
                 v[k] = agent_load(&status[b0 + k * DUP_THREADS]);
-                if (v[k] == 0 && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
+                if ((uint32_t)v[k] == 0u && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
                     at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
                     a.host_land[4 * view + CNT_STALL] = 1;
                     v[k] = 1;
                 }
             }
-            part += v[k] - 1;
+            part += (v[k] & 0xFFFFFFFFull) - 1;
+            part_ref += v[k] >> 32;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += (uint64_t)__shfl_xor((unsigned long long)part, d, 64);
-    __syncthreads();   // s_wave is reused
-    if (lane == 0) s_wave[w] = part;
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += (uint64_t)__shfl_xor((unsigned long long)part, d, 64);
+        part_ref += (uint64_t)__shfl_xor((unsigned long long)part_ref, d, 64);
+    }
+    __syncthreads();   // s_wave / s_ref are reused
+    if (lane == 0) { s_wave[w] = part; s_ref[w] = part_ref; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint64_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         s_base = base;
         if (blk == nblk - 1) {
-            // the frame's pair count: for the kernels that follow (device memory) and for the host, which reads it from mapped
-            // memory once this kernel has completed -- no copy command in the stream
+            // the frame's pair counts: for the kernels that follow (device memory) and for the host, which reads them from mapped
+            // memory once this kernel has completed -- no copy command in the stream.  CNT_NUM_RENDERED = pairs in the lists (what
+            // the sort, the range search and the arena capacity are about); LAND_NUM_REFERENCE = pairs of the reference's
+            // rectangles, the num_rendered the API reports (equal unless footprint clipping is on)
             uint64_t* cnt = at_view(a.counters, a.g_stride, view);
+            const uint64_t ref_total = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3] + block_ref;
             cnt[CNT_NUM_RENDERED] = base + block_total;
+            cnt[CNT_NUM_REFERENCE] = ref_total;
             a.host_land[4 * view + CNT_NUM_RENDERED] = base + block_total;
             a.host_land[4 * view + CNT_TRAP] = cnt[CNT_TRAP];
+            a.host_land[4 * view + LAND_NUM_REFERENCE] = ref_total;
             __threadfence_system();
         }
     }

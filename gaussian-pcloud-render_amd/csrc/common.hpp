@@ -79,6 +79,8 @@ constexpr int CNT_NUM_RENDERED = 0;  // true number of (tile, Gaussian) pairs, e
 constexpr int CNT_TRAP = 1;          // prefiltered = 1 but a Gaussian was culled
 constexpr int CNT_STALL = 2;         // the pair emission gave up waiting for a preceding workgroup's count (never expected;
                                      // cleared by k_preprocess, checked by the host: every spin in the library is bounded)
+constexpr int CNT_NUM_REFERENCE = 4; // pairs of the reference's unclipped tile rectangles = the num_rendered the API reports
+constexpr int LAND_NUM_REFERENCE = 3; // its slot in the host landing zone ([V][4]: CNT_NUM_RENDERED, CNT_TRAP, CNT_STALL, this)
 constexpr int CNT_BWD_DIRTY = 3;     // a backward has accumulated into this view's gradient records since the forward cleared
                                      // them: the next backward on the same arenas clears them first (k_bwd_items)
 

@@ -8,6 +8,7 @@
 // sort key (depth bits) is emitted directly, so nothing is re-read before the depth sort.
 #include "common.hpp"
 #include "splat_math.hpp"
+#include "tile_cull.hpp"
 
 namespace gsr {
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ uint32_t clamp_tile(float f, uint32_t grid)
 struct PreArgs {
     int P, D, M, W, H, V, vpt;            // vpt: views per thread (grid.y = ceil(V / vpt))
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
-    int prefiltered, need_backward;
+    int prefiltered, need_backward, reference_lists;
     uint32_t gridx, gridy;
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *campos;   // [V][16], [V][16], [V][3]
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         }
 
         int radius_out = 0;
-        uint32_t tiles = 0, key = 0xFFFFFFFFu, cmask = 0;
+        uint32_t tiles = 0, etiles = 0, key = 0xFFFFFFFFu, cmask = 0;
         uint2 rect = make_uint2(0, 0);
         Splat s;
         s.q0 = make_float4(0, 0, 0, 0);
@@ -200,6 +201,11 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                     tiles = ntiles;
                     key = __float_as_uint(p_view.z);
                     rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
+                    // the pairs this Gaussian EMITS: the reference's rectangle, clipped to where alpha can reach 1/255
+                    // (tile_cull.hpp); `tiles`, the reference's count, still goes into tiles_touched and num_rendered
+                    etiles = a.reference_lists ? ntiles
+                                               : clip_rect_to_footprint(px, py, cov_x, cov_y, cov_z, det, conic_x, conic_y, conic_z,
+                                                                        opacity, r, rect, a.gridx, a.gridy);
                     s.q0 = make_float4(px, py, conic_x, conic_y);
                     s.q1 = make_float4(conic_z, opacity, rgb.x, rgb.y);
                     s.q2 = make_float4(rgb.z, p_view.z, 0.f, 0.f);
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         at_view(a.dkey, a.g_stride, vw)[idx] = key;
         // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
         // Gaussian; the whole 64-B line is written here
-        const float4 q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(tiles), 0.f);
+        // (rectangle emitted, pairs emitted, pairs of the reference's rectangle)
+        const float4 q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(etiles), __uint_as_float(tiles));
         const int wave_first = idx - (int)(threadIdx.x & 63);
         const bool full_wave = wave_first + 64 <= a.P;   // wave-uniform
         if (full_wave) {
@@ -262,6 +269,7 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.scale_modifier = p.scale_modifier;
     a.prefiltered = p.prefiltered;
     a.need_backward = p.need_backward;
+    a.reference_lists = p.reference_lists;
     a.gridx = (uint32_t)((p.W + TILE_X - 1) / TILE_X);
     a.gridy = (uint32_t)((p.H + TILE_Y - 1) / TILE_Y);
     a.means3D = p.means3D; a.shs = p.shs; a.colors_precomp = p.colors_precomp; a.opacities = p.opacities;

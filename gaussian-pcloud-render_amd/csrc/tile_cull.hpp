@@ -59,6 +59,61 @@ __device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float
     return may_touch_rect(mx, my, A, B, C, o, x0, y0, x0 + 7.f, y0 + 7.f);
 }
 
+// ---- footprint clipping of a Gaussian's tile rectangle (pair emission) ---------------------------------------------
+// The reference emits one (tile, Gaussian) pair for every tile of the bounding SQUARE of radius ceil(3 sqrt(lambda_max))
+// (CR/auxiliary.h:46-56, CR/forward.cu:255-262), whatever the splat's shape and opacity.  A pixel only blends the splat when
+// alpha = o exp(power) >= 1/255, i.e. inside the ellipse  d^T conic d <= 2 log(255 o);  its axis-aligned bounding box is
+// |dx| <= sqrt(2 log(255 o) Sigma_xx), |dy| <= sqrt(2 log(255 o) Sigma_yy)  with Sigma the (dilated) 2D covariance the conic
+// was inverted from.  Tiles of the square that lie outside that box hold no pixel the reference would blend (it evaluates
+// them and skips them pixel by pixel, CR/forward.cu:336-347), so leaving them out of the lists changes no pixel, no
+// transmittance and no gradient -- only the private lists get shorter (a third of the pairs on the benchmark cloud:
+// anisotropic splats, opacities below one).  As for the quadrant test above, the clipping must be CONSERVATIVE against the
+// fp32 arithmetic of the per-pixel evaluation:
+//   * a blended pixel has power_fp32 >= -tau - 1e-6 (tau = log(255 o); rounding of o * exp(), of exp and of logf);
+//   * power_fp32 differs from the exact value of the quadratic form of the fp32 conic by at most a few ulp of its largest
+//     term; with |dx|, |dy| <= r + 16 inside the reference's rectangle that is far below
+//     E = 1e-5 (A + C + |B|) (r + 16)^2 + 1e-4 + 1e-5 tau  (the bound of may_touch_rect);
+//   * conic = adj(Sigma) / det_fp32, so the exact form is s d^T Sigma^-1 d with s = det_exact / det_fp32 >= 1 - eta,
+//     eta = 4e-7 (Sxx Syy + Sxy^2) / det (cancellation in the fp32 determinant), the element roundings being inside E;
+// hence |dx| <= sqrt(2 (tau + E) / (1 - eta) Sxx), widened by 1e-5 relative + 0.02 px for the square root and the products.
+// Anything that is not provably an ellipse (NaN, det <= 0, eta too large) keeps the reference's rectangle.
+// rect = (minx | miny << 16, maxx | maxy << 16) in tiles; returns the number of tiles left (0: the Gaussian emits nothing).
+__device__ __forceinline__ uint32_t clip_rect_to_footprint(float px, float py, float sxx, float sxy, float syy, float det,
+                                                            float A, float B, float C, float o, float r, uint2& rect,
+                                                            uint32_t gridx, uint32_t gridy)
+{
+    uint32_t minx = rect.x & 0xFFFFu, miny = rect.x >> 16, maxx = rect.y & 0xFFFFu, maxy = rect.y >> 16;
+    const uint32_t full = (maxx - minx) * (maxy - miny);
+    if (o < 1.0f / 255.0f) return 0u;      // alpha = o exp(power <= 0) <= o < 1/255 at every pixel (entries with power > 0 are skipped)
+    if (!(det > 0.f && sxx > 0.f && syy > 0.f && o <= 1.0e30f)) return full;   // (also NaN)
+    const float tau = logf(255.0f * o);
+    const float ext = r + 16.0f;
+    const float E = 1.0e-5f * ((A + C + fabsf(B)) * ext * ext) + 1.0e-4f + 1.0e-5f * tau;
+    const float eta = 4.0e-7f * (sxx * syy + sxy * sxy) / det;
+    if (!(eta < 0.25f) || !(E < 1.0e30f)) return full;
+    const float k = 2.0f * (tau + E) / (1.0f - eta);
+    const float hx = sqrtf(k * sxx) * (1.0f + 1.0e-5f) + 0.02f, hy = sqrtf(k * syy) * (1.0f + 1.0e-5f) + 0.02f;
+    if (!(hx >= 0.f && hy >= 0.f)) return full;
+    // pixel centres are integers: columns ceil(px - hx) .. floor(px + hx), rows likewise; their tiles, inside the rectangle
+    const float lim = 4.0e6f;
+    const float x_lo = fminf(fmaxf(ceilf(px - hx), -lim), lim), x_hi = fminf(fmaxf(floorf(px + hx), -lim), lim);
+    const float y_lo = fminf(fmaxf(ceilf(py - hy), -lim), lim), y_hi = fminf(fmaxf(floorf(py + hy), -lim), lim);
+    if (!(x_lo == x_lo && x_hi == x_hi && y_lo == y_lo && y_hi == y_hi)) return full;   // NaN mean
+    const int tx0 = (int)floorf(x_lo * (1.0f / 16.0f)), tx1 = (int)floorf(x_hi * (1.0f / 16.0f)) + 1;
+    const int ty0 = (int)floorf(y_lo * (1.0f / 16.0f)), ty1 = (int)floorf(y_hi * (1.0f / 16.0f)) + 1;
+    const uint32_t cx0 = tx0 < 0 ? 0u : ((uint32_t)tx0 > gridx ? gridx : (uint32_t)tx0);
+    const uint32_t cx1 = tx1 < 0 ? 0u : ((uint32_t)tx1 > gridx ? gridx : (uint32_t)tx1);
+    const uint32_t cy0 = ty0 < 0 ? 0u : ((uint32_t)ty0 > gridy ? gridy : (uint32_t)ty0);
+    const uint32_t cy1 = ty1 < 0 ? 0u : ((uint32_t)ty1 > gridy ? gridy : (uint32_t)ty1);
+    minx = minx > cx0 ? minx : cx0;
+    maxx = maxx < cx1 ? maxx : cx1;
+    miny = miny > cy0 ? miny : cy0;
+    maxy = maxy < cy1 ? maxy : cy1;
+    if (maxx <= minx || maxy <= miny) return 0u;
+    rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
+    return (maxx - minx) * (maxy - miny);
+}
+
 // Bounding rectangle, in lane coordinates (x = lane & 7, y = lane >> 3), of the lanes set in a ballot of an 8x8
 // quadrant wave.  Scalar code.  mask must not be 0.
 __device__ __forceinline__ void live_box(uint64_t mask, int& xmin, int& ymin, int& xmax, int& ymax)

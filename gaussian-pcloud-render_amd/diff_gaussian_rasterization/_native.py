@@ -9,6 +9,7 @@ call raises.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -22,7 +23,7 @@ class GsrParams(C.Structure):
     _fields_ = [
         ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
-        ("prefiltered", C.c_int), ("debug", C.c_int), ("need_backward", C.c_int),
+        ("prefiltered", C.c_int), ("debug", C.c_int), ("need_backward", C.c_int), ("reference_lists", C.c_int),
         ("bg", _fp), ("means3D", _fp), ("shs", _fp), ("colors_precomp", _fp), ("opacities", _fp),
         ("scales", _fp), ("rotations", _fp), ("cov3D_precomp", _fp),
         ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp),
@@ -33,12 +34,12 @@ class GsrParams(C.Structure):
 SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
            "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
-           "gsr_clock_probe_launch", "gsr_wall_clock_khz")
+           "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs")
 
 GSR_RETRY = 1
 
 Q = dict(DEPTHS=1, MEANS2D=2, CONIC_OPACITY=3, RGB=4, TILES_TOUCHED=5, POINT_LIST=6, POINT_LIST_KEYS=7, RANGES=8,
-         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, DEPTH_SORT=13)
+         FINAL_T=9, N_CONTRIB=10, CLAMPED=11, TILE_NEED=12, DEPTH_SORT=13, LIST_PAIRS=14)
 
 
 def _load():
@@ -92,6 +93,8 @@ def _load():
     lib.gsr_clock_probe_launch.argtypes = [_fp, C.c_int, _fp]
     lib.gsr_wall_clock_khz.restype = C.c_int
     lib.gsr_wall_clock_khz.argtypes = []
+    lib.gsr_last_list_pairs.restype = C.c_int
+    lib.gsr_last_list_pairs.argtypes = [C.POINTER(C.c_int64), C.c_int]
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
     return lib
@@ -146,9 +149,33 @@ def _params(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov
     p.W, p.H = int(W), int(H)
     p.tanfovx, p.tanfovy, p.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
     p.prefiltered, p.debug, p.need_backward = int(bool(prefiltered)), int(bool(debug)), int(bool(need_backward))
+    p.reference_lists = int(reference_lists())
     for k, t in keep.items():
         setattr(p, k, _ptr(t))
     return p, keep
+
+
+# ---- footprint clipping (include/gsr.h, gsr_params.reference_lists) ---------------------------------------------------
+# Default: a Gaussian emits pairs only for the tiles of the reference's rectangle in which it can reach alpha >= 1/255; every
+# API-visible result is unchanged.  set_reference_lists(True) / GSR_REFERENCE_LISTS=1 keeps the reference's full rectangles, so
+# that the private lists, ranges and n_contrib can be compared with the reference's element by element (parity tests).
+_REFERENCE_LISTS = [os.environ.get("GSR_REFERENCE_LISTS", "0") not in ("", "0")]   # process default
+_TLS = threading.local()                                                              # per-thread override (tests render from several threads)
+
+
+def reference_lists():
+    return getattr(_TLS, "reference_lists", _REFERENCE_LISTS[0])
+
+
+def set_reference_lists(on):
+    """Setting of the CALLING THREAD (None: back to the process default).  Returns the thread's previous override (or None)."""
+    old = getattr(_TLS, "reference_lists", None)
+    if on is None:
+        if hasattr(_TLS, "reference_lists"):
+            del _TLS.reference_lists
+    else:
+        _TLS.reference_lists = bool(on)
+    return old
 
 
 # ---- binning-arena capacity -----------------------------------------------------------------------------------------
@@ -392,14 +419,18 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
             binning = torch.empty((V * lib.gsr_binning_bytes(int(capacity)),), **byte)
             rc = submit(binning, 0)
             if rc == GSR_RETRY:
-                need = int(max(counts) * CAP_SLACK) + 4096
+                pairs = (C.c_int64 * V)()
+                _check(lib.gsr_last_list_pairs(pairs, V))
+                need = int(max(pairs) * CAP_SLACK) + 4096
                 binning = torch.empty((V * lib.gsr_binning_bytes(need),), **byte)
                 rc = submit(binning, 1)
             _check(rc)
         ov.give(out_color, radii, geom, binning, img, out_extra)
+        pairs = (C.c_int64 * V)()
+        _check(lib.gsr_last_list_pairs(pairs, V))   # (same host thread as the forward call: the count is kept per thread)
     del keep
     counts = [int(c) for c in counts]
-    _note_counts(key, counts)
+    _note_counts(key, [int(c) for c in pairs])      # the arena holds the lists: sized by their pairs, not by num_rendered
     if nx:
         return counts, out_color, radii, geom, binning, img, out_extra
     return counts, out_color, radii, geom, binning, img
@@ -522,13 +553,16 @@ _QSPEC = {
     "POINT_LIST_KEYS": (torch.int64, lambda P, R, T, N: (R,)), "RANGES": (torch.int32, lambda P, R, T, N: (T, 2)),
     "FINAL_T": (torch.float32, lambda P, R, T, N: (N,)), "N_CONTRIB": (torch.int32, lambda P, R, T, N: (N,)),
     "CLAMPED": (torch.uint8, lambda P, R, T, N: (P, 3)), "TILE_NEED": (torch.int32, lambda P, R, T, N: (T,)),
-    "DEPTH_SORT": (torch.int32, lambda P, R, T, N: (4,)),
+    "DEPTH_SORT": (torch.int32, lambda P, R, T, N: (4,)), "LIST_PAIRS": (torch.int64, lambda P, R, T, N: (2,)),
 }
 
 
 def query(name, P, W, H, R, geom, binning, img, view=0, n_views=1):
     """Copy one private arena array of `view` out of the arenas of an `n_views` batch (device tensor).  Unsigned data come
     back in same-width signed dtypes."""
+    if name in ("POINT_LIST", "POINT_LIST_KEYS"):
+        # the lists hold LIST_PAIRS[0] pairs: R (the reference's num_rendered) with reference_lists, fewer with footprint clipping
+        R = int(query("LIST_PAIRS", P, W, H, R, geom, binning, img, view=view, n_views=n_views)[0])
     dtype, shp = _QSPEC[name]
     T = ((W + 15) // 16) * ((H + 15) // 16)
     out = torch.zeros(shp(P, R, T, W * H), dtype=dtype, device=geom.device)

@@ -72,6 +72,15 @@ typedef struct gsr_params {
     int need_backward;     /* 0: inference call, skip the saves only gsr_backward reads (SH clamp mask,
                               accumulated colour, per-pixel state at the 1024-entry list boundaries);
                               gsr_backward is only valid after a forward with need_backward = 1      */
+    int reference_lists;   /* 0 (default): a Gaussian emits pairs for the tiles of the reference's rectangle
+                              (auxiliary.h:46-56) in which alpha can reach 1/255 -- the rectangle clipped to the
+                              bounding box of the ellipse  d^T conic d <= 2 log(255 opacity), conservatively against
+                              fp32 rounding (csrc/tile_cull.hpp).  The reference evaluates the other tiles' entries
+                              and skips them at every pixel (forward.cu:336-347), so out_color, radii, num_rendered
+                              and every gradient are the same bit for bit / sum for sum; only the PRIVATE lists
+                              (and the list positions in n_contrib) differ.  1: the reference's full rectangles --
+                              lists, ranges and n_contrib identical to the reference's (parity tests).
+                              (occupies what used to be padding: zero-initialised callers are unaffected)  */
     const float* bg;             /* [3]        device */
     const float* means3D;        /* [P,3]      device */
     const float* shs;            /* [P,M,3]    device or NULL */
@@ -99,10 +108,14 @@ size_t gsr_binning_bytes(int64_t num_rendered);
  * views by the reference's caller, simple_raw_render.py:259-278): per-Gaussian preprocess (cull, EWA projection, SH colour),
  * depth ordering, (tile, Gaussian) pair emission in depth order with its prefix sum, stable radix sort by tile, tile
  * ranges, per-tile front-to-back alpha compositing.  Writes radii[V,P], out_color[V,3,H,W] (planar CHW per view) and
- * num_rendered[V] (HOST array).  Nothing on the host waits for the device until every kernel of the batch is enqueued.
- * Returns GSR_OK, or GSR_RETRY when some num_rendered[v] exceeds the per-view capacity of `binning`: out_color is then
+ * num_rendered[V] (HOST array): the number of (tile, Gaussian) pairs of the reference's tile rectangles, i.e. exactly the
+ * reference's num_rendered (rasterizer_impl.cu:277-281).  The lists the library keeps hold at most that many pairs (fewer
+ * with footprint clipping, see gsr_params.reference_lists; gsr_last_list_pairs reports how many).
+ * Nothing on the host waits for the device until every kernel of the batch is enqueued.
+ * Returns GSR_OK, or GSR_RETRY when some view's lists exceed the per-view capacity of `binning`: out_color is then
  * invalid; call again with resume = 1, the same geom / image arenas and a binning arena of at least
- * V * gsr_binning_bytes(max_v num_rendered[v]) bytes (only the binning half of the frame is repeated). */
+ * V * gsr_binning_bytes(n) bytes, n = max_v num_rendered[v] (always enough) or max_v of gsr_last_list_pairs (exact)
+ * (only the binning half of the frame is repeated). */
 int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
                       void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered,
                       int resume, gsr_stream_t stream);
@@ -167,6 +180,10 @@ int gsr_backward(const gsr_params* p, const int* radii, int64_t num_rendered, co
                  float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                  float* dL_drot, gsr_stream_t stream);
 
+/* Pairs in the lists of the calling thread's last forward call, per view (out[V], HOST array): what a binning arena has to
+ * hold.  Equal to num_rendered with reference_lists = 1. */
+int gsr_last_list_pairs(int64_t* out, int V);
+
 /* present[i] = (view-space z of means3D[i] > 0.2)   (rasterizer_impl.cu:54-66) */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, gsr_stream_t stream);
@@ -179,13 +196,14 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 #define GSR_Q_CONIC_OPACITY 3  /* float  [P,4]                                                              */
 #define GSR_Q_RGB 4            /* float  [P,3]                                                              */
 #define GSR_Q_TILES_TOUCHED 5  /* uint32 [P]                                                                */
-#define GSR_Q_POINT_LIST 6     /* uint32 [R]   Gaussian ids sorted by (tile, depth bits, id)                */
-#define GSR_Q_POINT_LIST_KEYS 7/* uint64 [R]   (tile<<32)|depth bits, rebuilt for comparison with CUB keys  */
+#define GSR_Q_POINT_LIST 6     /* uint32 [L]   Gaussian ids sorted by (tile, depth bits, id); L = GSR_Q_LIST_PAIRS[0] (pass it as R) */
+#define GSR_Q_POINT_LIST_KEYS 7/* uint64 [L]   (tile<<32)|depth bits, rebuilt for comparison with CUB keys  */
 #define GSR_Q_RANGES 8         /* uint32 [T,2]                                                              */
 #define GSR_Q_FINAL_T 9        /* float  [H*W]                                                              */
 #define GSR_Q_N_CONTRIB 10     /* uint32 [H*W]                                                              */
 #define GSR_Q_TILE_NEED 12     /* uint32 [T]   list entries the tile's render actually walked (roofline model)    */
 #define GSR_Q_CLAMPED 11       /* uint8  [P,3]                                                              */
+#define GSR_Q_LIST_PAIRS 14    /* uint64 [2]   pairs in the view's lists, pairs of the reference's rectangles      */
 #define GSR_Q_DEPTH_SORT 13    /* uint32 [4]   depth sort of the frame: key base, key bits compared, passes run, -  */
 int gsr_query(const gsr_params* p, int what, const void* geom, const void* binning, size_t binning_bytes, const void* image,
               int64_t num_rendered, void* dst, size_t dst_bytes, gsr_stream_t stream);

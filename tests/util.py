@@ -183,10 +183,23 @@ def seeded_dL(scene, seed=123):
 
 
 # ------------------------------------------------------------------------------------------ product runner
-def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None, light=False):
+def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None, light=False, reference_lists=True):
     """Run the HIP library through the package's native binding; returns (forward dict, grads dict or None) with the
     same keys/shapes as oracle.Oracle.forward.  light=True skips the copies of the private arena arrays (only R, the
-    image and radii are returned): for full-size scenes where they are not compared."""
+    image and radii are returned): for full-size scenes where they are not compared.
+    reference_lists=True (the default HERE, not in the product): the reference's full tile rectangles are emitted, so the
+    private lists / ranges / n_contrib can be compared with the reference's element by element.  False = the product's default,
+    footprint clipping (include/gsr.h): every API-visible result must be the same, the lists are sub-lists ("L" pairs instead
+    of "R"); check_clipped_equivalent below holds the two modes against each other."""
+    from diff_gaussian_rasterization import _native as N
+    old = N.set_reference_lists(reference_lists)
+    try:
+        return _run_product(scene, device, dL_dpix, debug, need_backward, light)
+    finally:
+        N.set_reference_lists(old)
+
+
+def _run_product(scene, device, dL_dpix, debug, need_backward, light):
     import torch
     from diff_gaussian_rasterization import _native as N
 
@@ -201,9 +214,13 @@ def run_product(scene, device, dL_dpix=None, debug=False, need_backward=None, li
     R, color, radii, geom, binning, img = N.rasterize_gaussians(*args, need_backward=nb)
     P, W, H = scene.P, scene.W, scene.H
     out = dict(P=P, W=W, H=H, R=R, out_color=color.cpu().numpy(), radii=radii.cpu().numpy())
+    if P:
+        lp = N.query("LIST_PAIRS", P, W, H, R, geom, binning, img).cpu().numpy()
+        out["L"] = int(lp[0])                       # pairs in the library's lists (<= R with footprint clipping)
+        assert int(lp[1]) == R, "the device's reference pair count differs from the reported num_rendered"
     if P and not light:
         def q(name):
-            return N.query(name, P, W, H, R, geom, binning, img).cpu().numpy()
+            return N.query(name, P, W, H, out["L"], geom, binning, img).cpu().numpy()
         out.update(
             depths=q("DEPTHS"), means2D=q("MEANS2D"), conic_opacity=q("CONIC_OPACITY"), rgb=q("RGB"),
             tiles_touched=q("TILES_TOUCHED").view(np.uint32), vals=q("POINT_LIST").view(np.uint32),
@@ -280,3 +297,67 @@ def check_grads(gp, go, tag, names=GRAD_NAMES, whole_tensor=WHOLE_TENSOR):
             b64 = np.asarray(b, np.float64).reshape(a.shape)
             dmax, scale = np.abs(np.asarray(a, np.float64) - b64).max(), np.abs(b64).max()
             assert dmax <= whole_tensor * scale + 1e-30, "%s %s: max|a - b| = %.3g > %.1e * max|b| = %.3g" % (tag, k, dmax, whole_tensor, whole_tensor * scale)
+
+
+# ---------------------------------------------------------------------------------------------- footprint clipping
+def _tile_lists(p):
+    T = p["ranges"].shape[0]
+    return [p["vals"][p["ranges"][t, 0]:p["ranges"][t, 1]] for t in range(T)]
+
+
+def check_clipped_equivalent(a, b, tag, check_dead=True):
+    """a: a run with the reference's full lists (reference_lists=True), b: the same scene with footprint clipping (the product's
+    default).  Everything the API returns must be identical bit for bit; b's lists must be a's with entries REMOVED (same
+    order), every removed (tile, Gaussian) pair must be one the reference skips at every pixel of the tile -- replayed here in
+    float32 with the reference's expression order (CR/forward.cu:328-347) from the bit-exact per-Gaussian values -- and
+    n_contrib must point at the same Gaussian through the shorter lists.  Returns (pairs kept, pairs of the reference)."""
+    assert b["R"] == a["R"], tag + ": num_rendered must stay the reference's count"
+    np.testing.assert_array_equal(a["radii"], b["radii"], err_msg=tag + " radii")
+    assert a["out_color"].tobytes() == b["out_color"].tobytes(), tag + ": out_color differs between full and clipped lists"
+    if a["P"] == 0:
+        return 0, 0
+    assert a["L"] == a["R"] and b["L"] <= a["R"], tag
+    if "vals" not in a or "vals" not in b:
+        return b["L"], a["R"]
+    np.testing.assert_array_equal(a["tiles_touched"], b["tiles_touched"], err_msg=tag + " tiles_touched")
+    assert a["final_T"].tobytes() == b["final_T"].tobytes(), tag + ": final_T"
+    for k in ("means2D", "depths", "conic_opacity", "rgb"):
+        assert a[k].tobytes() == b[k].tobytes(), tag + ": " + k
+    W, H = a["W"], a["H"]
+    gx = (W + 15) // 16
+    la, lb = _tile_lists(a), _tile_lists(b)
+    m2, co = a["means2D"].astype(np.float32), a["conic_opacity"].astype(np.float32)
+    half, cut = np.float32(-0.5), np.float32(1.0) / np.float32(255.0)
+    nca = a["n_contrib"].astype(np.int64)
+    ncb = b["n_contrib"].astype(np.int64)
+    for t in range(len(la)):
+        fa, fb = la[t], lb[t]
+        if fa.size == fb.size:
+            assert np.array_equal(fa, fb), "%s: tile %d lists differ" % (tag, t)
+            pos = np.arange(1, fa.size + 1)
+        else:
+            # fb must be a subsequence of fa: greedy matching (ids can repeat in neither list: one pair per (tile, Gaussian))
+            assert fb.size < fa.size, "%s: tile %d: clipped list longer than the reference's" % (tag, t)
+            keep = np.isin(fa, fb)
+            assert np.array_equal(fa[keep], fb), "%s: tile %d: clipped list is not the reference's list with entries removed" % (tag, t)
+            pos = np.nonzero(keep)[0] + 1              # 1-based reference position of every kept entry
+            if check_dead:
+                ids = fa[~keep]
+                ty, tx = divmod(t, gx)
+                xs = np.arange(tx * 16, min(tx * 16 + 16, W), dtype=np.float32)[None, None, :]
+                ys = np.arange(ty * 16, min(ty * 16 + 16, H), dtype=np.float32)[None, :, None]
+                A, B, C, o = (co[ids, k][:, None, None] for k in range(4))
+                dx, dy = m2[ids, 0][:, None, None] - xs, m2[ids, 1][:, None, None] - ys
+                power = half * (A * dx * dx + C * dy * dy) - B * dx * dy          # float32 throughout, one rounding per operation
+                with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+                    alpha = o * np.exp(power)
+                live = (~(power > 0)) & ~(alpha < cut * np.float32(1.0 - 1e-5))   # (1e-5: glibc vs ocml expf, last bit)
+                assert not live.any(), "%s: tile %d: a removed pair reaches alpha >= 1/255 (Gaussian %d)" % (
+                    tag, t, int(ids[np.nonzero(live.any((1, 2)))[0][0]]))
+        # n_contrib: b's list position -> the reference's
+        ty, tx = divmod(t, gx)
+        ya, yb, xa, xb = ty * 16, min(ty * 16 + 16, H), tx * 16, min(tx * 16 + 16, W)
+        nb = ncb[ya:yb, xa:xb]
+        mapped = np.where(nb > 0, np.concatenate([[0], pos])[np.minimum(nb, pos.size)], 0)
+        assert np.array_equal(mapped, nca[ya:yb, xa:xb]), "%s: tile %d: n_contrib does not map back to the reference's positions" % (tag, t)
+    return b["L"], a["R"]
