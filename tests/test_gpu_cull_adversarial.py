@@ -153,3 +153,12 @@ def test_splats_grazing_the_alpha_cut_on_every_quadrant_edge(variant, oracle, gp
     gr = dict(gr)
     gr["dL_dopacity"] = gr["dL_dopacity"].reshape(gp["dL_dopacity"].shape)
     util.check_grads(gp, gr, "grazing splats, variant %d" % variant)
+    # --- the same sweep against footprint clipping (the product's default list construction, csrc/tile_cull.hpp
+    # clip_rect_to_footprint): a quarter of the targeted quadrants lie on their tile's left / top edge with the splat's mean in the
+    # neighbouring tile, so the clipped rectangle's edge is decided by the very pixel column / row the sweep grazes
+    c, gc = run_product(s, gpu_device, dL_dpix=dL, reference_lists=False)
+    kept, total = util.check_clipped_equivalent(p, c, "grazing splats, variant %d, clipped lists" % variant)
+    assert c["final_T"].tobytes() == r["final_T"].tobytes() and c["out_color"].tobytes() == r["out_color"].tobytes()
+    assert kept < total, "no pair was clipped: the sweep does not exercise the clipping"
+    util.check_grads(gc, gr, "grazing splats, variant %d, clipped lists" % variant)
+    print("variant %d: clipped lists keep %d of %d pairs" % (variant, kept, total))

@@ -8,6 +8,8 @@ one and against the reference build / oracle on every scene, on random cases and
   * n_contrib: the same Gaussian through the shorter lists;
   * gradients: inside the usual bars against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -67,7 +69,7 @@ def test_public_api_default_is_clipped_and_matches_the_reference_build(gpu_devic
     assert np.array_equal(radii.cpu().numpy(), r["radii"])
 
 
-N_FUZZ = 96
+N_FUZZ = int(os.environ.get("GSR_FOOTPRINT_FUZZ_CASES", "96"))   # (a 6 000-case run: profiles/r04_footprint_clipping.txt)
 
 
 @pytest.mark.parametrize("i", range(N_FUZZ))
