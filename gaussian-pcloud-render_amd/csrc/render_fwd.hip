@@ -198,6 +198,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 #ifdef GSR_STATS
     FW_T(tw0);
     unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;
+    unsigned live_cnt = 64, n_pairs_le8 = 0, n_pairs_le16 = 0, n_pairs_le32 = 0;   // pairs evaluated while <= 8 / 16 / 32 pixels were live
 #endif
     static_assert(NX == 0 || NX == 4 || NX == 8, "extra channels come in quads");
     constexpr int PW = PAIR_WORDS + 2 * NX;   // words per staged pair
@@ -255,6 +256,9 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     bool crossed = false;  // this quadrant walked past a BWD_CHUNK boundary (wave-uniform)
     bool done = !inside;
     bool all_done = __all(done);
+#ifdef GSR_STATS
+    live_cnt = (unsigned)__popcll(__ballot(!done));
+#endif
     if (!all_done) {
         int ax, ay, bx, by;
         live_box(__ballot(!done), ax, ay, bx, by);
@@ -365,6 +369,9 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 // Pair p+1 is read from LDS while pair p is evaluated.  The loop body is written out twice with the two
                 // register sets swapped, so no register moves are needed to rotate them.
                 auto eval_pair = [&](const PairRec<NX>& r) {
+#ifdef GSR_STATS
+                    n_pairs_le8 += live_cnt <= 8; n_pairs_le16 += live_cnt <= 16; n_pairs_le32 += live_cnt <= 32;
+#endif
                     // this pair has landed (DS returns in order); the 5 + NX / 2 reads of the next pair stay in flight
                     __builtin_amdgcn_s_waitcnt(NX == 0 ? 0xC57F : NX == 4 ? 0xC77F : 0xC97F);   // lgkmcnt(5 / 7 / 9)
                     // alpha of each entry; ae = alpha where the entry counts for this pixel, else 0.  The two entries
@@ -426,6 +433,9 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                         done = done || s0 || s1;
                         const uint64_t live = __ballot(!done);
                         all_done = live == 0;
+#ifdef GSR_STATS
+                        live_cnt = (unsigned)__popcll(live);
+#endif
                         if (!all_done) {   // a pixel stopped: the rounds still to come only need entries that reach the rest
                             int ax, ay, bx, by;
                             live_box(live, ax, ay, bx, by);
@@ -478,6 +488,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
         unsigned* r_ = g_fwd_rec[blockIdx.x];
         r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_stage; r_[3] = (unsigned)tw_eval;
         r_[4] = 1u; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_pairs;
+        r_[7] = n_pairs_le8 | (n_pairs_le16 << 10) | (n_pairs_le32 << 20);   // (10 bits each: a wave evaluates < 1024 pairs)
         g_fwd_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492) | (__builtin_amdgcn_s_getreg(63508) << 28);   // HW_ID, XCC_ID
         g_fwd_hw[blockIdx.x][1] = (unsigned)tw0;
     }
