@@ -462,7 +462,7 @@ int launch_tile_order(const Launch& L, const Batch& B, int T)
 // records were already consumed by a backward (CNT_BWD_DIRTY, raised by k_render_backward as it starts) they clear them before the
 // render backward accumulates again; normally they read one word and leave.
 constexpr int BWD_CLEAR_BLOCKS = 64;
-__global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,
+__global__ __launch_bounds__(1024) void k_bwd_items(int T, int chunk_shift, const uint32_t* __restrict__ need, uint32_t* __restrict__ items,
                                                     uint32_t* __restrict__ count, size_t iv_stride, const uint64_t* __restrict__ counters,
                                                     size_t g_stride, float* __restrict__ grad_rec, size_t gr_stride, size_t gr_bytes)
 {
@@ -480,14 +480,14 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __res
     const uint32_t lane = threadIdx.x & 63;
     if (threadIdx.x < ORD_BUCKETS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t full_bucket = work_bucket(BWD_CHUNK);
+    const uint32_t full_bucket = work_bucket(1u << chunk_shift);
     for (int pass = 0; pass < 2; pass++) {
         for (int t = threadIdx.x; t < T; t += 1024) {
             const uint32_t n = need[t];
             if (n == 0) continue;
-            uint32_t n_full = n >> BWD_CHUNK_SHIFT;
+            uint32_t n_full = n >> chunk_shift;
             if (n_full > BWD_MAX_CHUNKS - 1) n_full = BWD_MAX_CHUNKS - 1;
-            const uint32_t rest = n - (n_full << BWD_CHUNK_SHIFT);   // size of the tile's last item (may exceed BWD_CHUNK)
+            const uint32_t rest = n - (n_full << chunk_shift);   // size of the tile's last item (may exceed the chunk length)
             if (pass == 0) {
                 if (n_full) atomicAdd(&cnt[full_bucket], n_full);
                 if (rest) atomicAdd(&cnt[work_bucket(rest)], 1u);
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, const uint32_t* __res
 
 int launch_bwd_items(const Launch& L, const Batch& B, int T, int P)
 {
-    hipLaunchKernelGGL(k_bwd_items, dim3(B.V, 1 + BWD_CLEAR_BLOCKS), dim3(1024), 0, L.stream, T, B.iv.tile_need, B.iv.bwd_items,
+    hipLaunchKernelGGL(k_bwd_items, dim3(B.V, 1 + BWD_CLEAR_BLOCKS), dim3(1024), 0, L.stream, T, B.chunk_shift(), B.iv.tile_need, B.iv.bwd_items,
                        B.iv.bwd_count, B.iv_stride, B.g.counters, B.g_stride, B.grad_rec, B.gr_stride, grad_rec_bytes(P));
     return check_launch(L, "bwd_items");
 }

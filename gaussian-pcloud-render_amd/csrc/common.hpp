@@ -104,10 +104,14 @@ struct GeomView {
 
 // Backward work items: a tile's consumed list is cut into chunks of BWD_CHUNK entries that different waves walk
 // concurrently; the forward pass leaves the per-pixel state (T, accumulated colour) at every chunk boundary it crosses.
-constexpr int BWD_CHUNK = 1024;
-constexpr int BWD_CHUNK_SHIFT = 10;
-constexpr int BWD_MAX_CHUNKS = 16;   // per tile; the last one takes whatever is left
-constexpr int BWD_TILE_BITS = 28;    // item = tile | chunk << 28 (check_params limits images to 2^28 tiles)
+// The chunk length depends on the views per submission (both halves of a frame see the same V, so both derive the same length):
+// a single view's backward launch ends on its longest serial walks and wants them short -- 0.267 / 0.236 / 0.229 ms per view with
+// chunks of 1024 / 512 / 256 entries, against 0.012 / 0.016 / 0.019 ms for the item list -- while a 12-view launch hides them behind
+// the other views' work and pays for the extra items and boundary states instead (0.207 / 0.215 ms per view with 1024 / 512).
+constexpr int BWD_CHUNK_SHIFT_MIN = 9;     // the binning arena's boundary-state area is carved for this length
+__host__ __device__ inline int bwd_chunk_shift(int V) { return V >= 8 ? 10 : 9; }
+constexpr int BWD_MAX_CHUNKS = 32;   // per tile; the last one takes whatever is left
+constexpr int BWD_TILE_BITS = 27;    // item = tile | chunk << 27 (check_params limits images to 2^27 tiles)
 
 // The binning arena is carved by CAPACITY (pairs), not by the frame's pair count: the count only exists on the device
 // while the frame is being enqueued (no host round trip), and forward and backward must carve identically, so both derive
@@ -117,8 +121,8 @@ struct BinView {
     uint32_t* val[2];  // [cap] Gaussian ids, ping-pong
     uint32_t* hist;    // [RADIX * nblk(cap)]
     uint32_t* totals;  // [RADIX]
-    float4* ckpt;      // [(cap / BWD_CHUNK + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
-                       // range.x + k * BWD_CHUNK, slot (range.x >> BWD_CHUNK_SHIFT) + k  (unique: lists do not overlap)
+    float4* ckpt;      // [((cap >> BWD_CHUNK_SHIFT_MIN) + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
+                       // range.x + k * chunk, slot (range.x >> chunk shift) + k  (unique: lists do not overlap)
     int64_t cap;
     size_t bytes;
 };
@@ -182,7 +186,7 @@ inline BinView bin_view(void* base, int64_t cap)
     carve(cur, b.val[1], r);
     carve(cur, b.hist, RADIX * nblk);
     carve(cur, b.totals, (size_t)RADIX);
-    carve(cur, b.ckpt, (r / BWD_CHUNK + 2) * 256);
+    carve(cur, b.ckpt, ((r >> BWD_CHUNK_SHIFT_MIN) + 2) * 256);
     b.cap = (int64_t)r;
     b.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
     return b;
@@ -242,6 +246,7 @@ struct Launch {
 // One batch of V views: the view-0 carving of each arena plus the byte stride to the next view's arena.
 struct Batch {
     int V;
+    int chunk_shift() const { return bwd_chunk_shift(V); }   // log2 of the backward work items' length (list entries)
     GeomView g;
     size_t g_stride;
     ImageView iv;

@@ -288,7 +288,7 @@ struct RenderBwdArgs {
     const float* accum;          // [3N] forward accumulated colour without background
     const uint32_t* point_list;
     const Splat* splat;
-    int W, H, gridx, num_tiles;
+    int W, H, gridx, num_tiles, chunk_shift;
     const float* bg;
     const float* final_T;
     const uint32_t* n_contrib;
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         total = (int)__builtin_amdgcn_readfirstlane(m);   // every lane holds the maximum: tell the compiler it is uniform
     }
     // this item's slice of the list: entries [lo, hi0), walked last first
-    const int lo = (int)(chunk << BWD_CHUNK_SHIFT);
+    const int lo = (int)(chunk << a.chunk_shift);
     if (lo >= total) continue;
-    const bool last_chunk = chunk == BWD_MAX_CHUNKS - 1 || lo + BWD_CHUNK >= total;
-    const int hi0 = last_chunk ? total : lo + BWD_CHUNK;
+    const bool last_chunk = chunk == BWD_MAX_CHUNKS - 1 || lo + (1 << a.chunk_shift) >= total;
+    const int hi0 = last_chunk ? total : lo + (1 << a.chunk_shift);
 
     const uint2 range = a.ranges[tile];
     const float T_final = inside ? a.final_T[pix] : 0.f;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     float s_rec = 0.f;                        // accum_rec . dL_dpixel
     float last_alpha = 0.f, last_d = 0.f;     // last alpha, last_color . dL_dpixel
     if (!last_chunk && last_contributor > (uint32_t)hi0) {
-        const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)(hi0 >> BWD_CHUNK_SHIFT);
+        const size_t slot = (size_t)(range.x >> a.chunk_shift) + (size_t)(hi0 >> a.chunk_shift);
         const float4 ck = a.ckpt[slot * 256 + q * 64 + lane];
         T = ck.x;
         const float behind = (a.accum[pix] - ck.y) * dpx0 + (a.accum[N + pix] - ck.z) * dpx1 + (a.accum[2 * N + pix] - ck.w) * dpx2;
@@ -743,6 +743,7 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     a.grad_rec = B.grad_rec; a.gr_stride = B.gr_stride;
     a.counters = B.g.counters;
     a.num_tiles = a.gridx * gridy;
+    a.chunk_shift = B.chunk_shift();
     a.V = (uint32_t)B.V;
     a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;
     // the number of items is only known on the device: every view gets the same number of workgroup quartets, enough in

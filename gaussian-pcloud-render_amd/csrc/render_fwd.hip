@@ -37,7 +37,7 @@ struct RenderArgs {
     const uint32_t* tile_order;
     const uint32_t* point_list;
     const Splat* splat;
-    int W, H, gridx, num_tiles;
+    int W, H, gridx, num_tiles, chunk_shift;
     const float* bg;
     float* out_color;
     float* final_T;
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
             }
 
             // backward work items are chunks of BWD_CHUNK list entries: leave this quadrant's state at the boundaries it crosses
-            if (a.ckpt != nullptr && base != 0 && (base & (BWD_CHUNK - 1)) == 0 && (base >> BWD_CHUNK_SHIFT) < BWD_MAX_CHUNKS) {
-                const size_t slot = (size_t)(range.x >> BWD_CHUNK_SHIFT) + (size_t)(base >> BWD_CHUNK_SHIFT);
+            if (a.ckpt != nullptr && base != 0 && (base & ((1 << a.chunk_shift) - 1)) == 0 && (base >> a.chunk_shift) < BWD_MAX_CHUNKS) {
+                const size_t slot = (size_t)(range.x >> a.chunk_shift) + (size_t)(base >> a.chunk_shift);
                 a.ckpt[slot * 256 + q * 64 + lane] = make_float4(T, C01.x, C01.y, C2);
                 crossed = true;
             }
@@ -550,6 +550,7 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;
     const int T = a.gridx * gridy;
     a.num_tiles = T;
+    a.chunk_shift = B.chunk_shift();
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
     a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr;
     const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);

@@ -35,9 +35,10 @@ def test_arena_size_queries():
     # SoA arena: 64-B splat line + 64-B gradient record + depth keys/ids/tile count/clamp mask per Gaussian -> ~149 B/Gaussian
     # + per-workgroup histograms and prefix-sum status words
     assert 140 * 800_000 < lib.gsr_geom_bytes(800_000) < 160 * 800_000
-    # binning: two key + two u32 id buffers (16 B/pair) + the backward pass's chunk-boundary state (4 KB per 1024
-    # pairs = 4 B/pair); the reference needs 24 B/pair + CUB temp
-    assert 20 * 11_500_000 <= lib.gsr_binning_bytes(11_500_000) < 21 * 11_500_000
+    # binning: two key + two u32 id buffers (16 B/pair) + the backward pass's chunk-boundary state (4 KB per 512
+    # pairs = 8 B/pair: carved for the shortest chunk length, the one single-view submissions use); the reference needs
+    # 24 B/pair + CUB temp -- for 1.5x the pairs (footprint clipping)
+    assert 24 * 11_500_000 <= lib.gsr_binning_bytes(11_500_000) < 25 * 11_500_000
     assert lib.gsr_binning_bytes(0) > 0
     assert lib.gsr_image_bytes(1920, 1080) >= 20 * 1920 * 1080 + 8 * 8160
     # sizes that do not fit int32 pair counts are still answered
