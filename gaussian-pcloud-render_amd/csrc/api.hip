@@ -266,6 +266,8 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
             SortJob job{{B.g.dkey[0], B.g.dkey[1]}, {B.g.dval[0], B.g.dval[1]}, B.g.hist, B.g.totals, B.g_stride, nullptr, 0, p->P, V};
             job.blk_minmax = B.g.blk_minmax;
             job.sortctl = B.g.sortctl;
+            // half-size sort blocks while whole-size ones would leave the chip short of workgroups
+            job.small_blocks = div_up(p->P, RS_TILE) * V < 4096;
             int res = 0;
             if (int e = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 32, &res)) return e;
             // up to 4 passes (B.g.sortctl says how many did something): the ids in depth order are in dval[passes & 1]

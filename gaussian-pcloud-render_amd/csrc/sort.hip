@@ -80,11 +80,12 @@ __device__ __forceinline__ int64_t view_count(const SortView& sv, uint32_t view)
 // than the partial-line stores they save: 61 vs 55 us per launch at 12 views x 11.8 M pairs, 36 vs 11 us for the depth keys.)
 constexpr int HIST_GROUP = 16;
 
-template <typename KeyT>
+template <typename KeyT, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restrict__ keys, SortView sv, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ hist, int nblk_pad,
                                                            uint32_t* __restrict__ minmax)   // depth sort, pass 0: [2][nblk_pad], else NULL
 {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const uint32_t view = blockIdx.y;
     uint32_t kbase;
     if (!pass_control(sv, view, shift, kbase)) return;
@@ -232,7 +233,7 @@ int debug_scatter_times(unsigned long long* out8, int reset)
 #endif
 
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
-template <int BITS, typename KeyT>
+template <int BITS, typename KeyT, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index
                                                               KeyT* __restrict__ keys_out,
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
                                                               uint32_t mask, const uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ totals, int nblk_pad)
 {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const uint32_t view = blockIdx.y;
     uint32_t kbase;
     if (!pass_control(sv, view, shift, kbase)) return;
@@ -392,8 +394,10 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
 {
     int cur = 0;
     if (job.cap > 0 && job.V > 0) {
-        const int nblk = (int)div_up(job.cap, RS_TILE);
-        const int nblk_pad = sort_hist_stride(job.cap);
+        const bool small = job.small_blocks && !key16 && end_bit % RADIX_BITS == 0;   // (every digit 8 bits wide)
+        const int tile = small ? RS_TILE_SMALL : RS_TILE;
+        const int nblk = (int)div_up(job.cap, tile);
+        const int nblk_pad = sort_hist_stride(job.cap, tile);
         SortView sv{job.stride, job.n_dev, job.n_stride, job.cap, nullptr};
         const dim3 grid_hist(nblk_pad, job.V);
         const dim3 grid((unsigned)div_up(nblk, 8 * HIST_GROUP) * 8 * HIST_GROUP, job.V);   // see the workgroup -> block map
@@ -408,10 +412,13 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
             sv.ctl = (job.sortctl != nullptr && pass > 0) ? job.sortctl : nullptr;
             uint32_t* minmax = make_ctl ? job.blk_minmax : nullptr;
             if (key16)
-                hipLaunchKernelGGL(k_radix_hist<uint16_t>, grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint16_t*)job.key[cur], sv,
+                hipLaunchKernelGGL((k_radix_hist<uint16_t, RS_ITEMS>), grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint16_t*)job.key[cur], sv,
+                                   shift, mask, job.hist, nblk_pad, minmax);
+            else if (small)
+                hipLaunchKernelGGL((k_radix_hist<uint32_t, RS_ITEMS_SMALL>), grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint32_t*)job.key[cur], sv,
                                    shift, mask, job.hist, nblk_pad, minmax);
             else
-                hipLaunchKernelGGL(k_radix_hist<uint32_t>, grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint32_t*)job.key[cur], sv,
+                hipLaunchKernelGGL((k_radix_hist<uint32_t, RS_ITEMS>), grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint32_t*)job.key[cur], sv,
                                    shift, mask, job.hist, nblk_pad, minmax);
             if (int e = check_launch(L, "radix_hist")) return e;
             hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1u + (make_ctl ? 1u : 0u), job.V), dim3(256), 0, L.stream, job.hist,
@@ -421,15 +428,19 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
 #define GSR_SCATTER(B)                                                                                                        \
     case B:                                                                                                                   \
         if (key16)                                                                                                            \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t>), grid, dim3(RS_THREADS), 0, L.stream,                           \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t, RS_ITEMS>), grid, dim3(RS_THREADS), 0, L.stream,                 \
                                (const uint16_t*)job.key[cur], vin, (uint16_t*)job.key[cur ^ 1], job.val[cur ^ 1], sv, shift,  \
                                mask, job.hist, job.totals, nblk_pad);                                                         \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t>), grid, dim3(RS_THREADS), 0, L.stream,                           \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t, RS_ITEMS>), grid, dim3(RS_THREADS), 0, L.stream,                 \
                                (const uint32_t*)job.key[cur], vin, job.key[cur ^ 1], job.val[cur ^ 1], sv, shift, mask,       \
                                job.hist, job.totals, nblk_pad);                                                               \
         break;
-            switch (bits) {
+            if (small)
+                hipLaunchKernelGGL((k_radix_scatter<RADIX_BITS, uint32_t, RS_ITEMS_SMALL>), grid, dim3(RS_THREADS), 0, L.stream,
+                                   (const uint32_t*)job.key[cur], vin, job.key[cur ^ 1], job.val[cur ^ 1], sv, shift, mask, job.hist,
+                                   job.totals, nblk_pad);
+            else switch (bits) {
                 GSR_SCATTER(1) GSR_SCATTER(2) GSR_SCATTER(3) GSR_SCATTER(4) GSR_SCATTER(5) GSR_SCATTER(6) GSR_SCATTER(7)
                 GSR_SCATTER(8)
             }
