@@ -15,6 +15,7 @@
 // Tile ranges (reference CR/rasterizer_impl.cu:116-138 identifyTileRanges + the memset at :310): one thread per tile finds
 // its list in the sorted keys by binary search -- T searches instead of a pass over all R keys.
 #include "common.hpp"
+#include "tile_cull.hpp"
 
 namespace gsr {
 
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     __shared__ uint32_t s_off[4][64];
     __shared__ uint32_t s_id[4][64];
     __shared__ uint2 s_rect[4][64];
+    __shared__ uint32_t s_sp2[4][64];
+    __shared__ uint2 s_pre[4][64];
     __shared__ uint32_t s_flag[4][64];
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_ref[4];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     // A wave owns DUP_G groups of 64 consecutive Gaussians (positions in depth order); the G gathers are independent and in
     // flight together, and the ticket and the look-back -- round trips to the fabric that bound a workgroup's life -- are paid
     // once per DUP_G * 256 Gaussians.
-    uint32_t cnt[DUP_G], id[DUP_G];
+    uint32_t cnt[DUP_G], id[DUP_G], sp2[DUP_G];
     uint2 rc[DUP_G];
     uint64_t ref_cnt = 0;   // pairs of the reference's (unclipped) rectangles: only their total is needed (num_rendered)
     const int slot0 = (int)(blk * DUP_BLOCK + w * (64 * DUP_G) + lane);
@@ -116,11 +119,23 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     for (int g = 0; g < DUP_G; g++) {
         cnt[g] = 0;
         rc[g] = make_uint2(0, 0);
+        sp2[g] = 0;
         if (slot0 + g * 64 < a.P) {
             const float4 q3 = splat[id[g]].q3;   // one 16-B gather: tile rectangle + tile count
+            const uint32_t w3 = __float_as_uint(q3.w);
             rc[g] = make_uint2(__float_as_uint(q3.x), __float_as_uint(q3.y));
-            cnt[g] = __float_as_uint(q3.z);
-            ref_cnt += __float_as_uint(q3.w);
+            sp2[g] = __float_as_uint(q3.z);
+            if (w3 & SPANS_FLAG) {
+                // row spans: one byte per tile row (first column | columns << 4); the pair count is the sum of the high nibbles
+                const uint32_t a4 = (rc[g].y >> 4) & 0x0F0F0F0Fu, b4 = (sp2[g] >> 4) & 0x0F0F0F0Fu;
+                const uint32_t pa = a4 * 0x01010101u;              // byte i = columns of rows 0..i (<= 60)
+                const uint32_t pb = b4 * 0x01010101u + (pa >> 24) * 0x01010101u;   // rows 0..4+i (<= 120)
+                cnt[g] = pb >> 24;
+                id[g] |= SPANS_FLAG;                               // travels with the id (ids are < 2^31)
+            } else {
+                cnt[g] = sp2[g];
+            }
+            ref_cnt += w3 & ~SPANS_FLAG;
         }
     }
     // ---- prefix sum: inside the wave (group after group), over the workgroup's waves, over the preceding workgroups ----
@@ -221,12 +236,12 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
 #pragma unroll 1
     for (int g = 0; g < DUP_G; g++) {
         // select group g's registers without dynamic indexing
-        uint32_t cnt_g = cnt[0], id_g = id[0];
+        uint32_t cnt_g = cnt[0], id_g = id[0], sp2_g = sp2[0];
         uint2 rc_g = rc[0];
         uint64_t ex_g = excl[0];
 #pragma unroll
         for (int k = 1; k < DUP_G; k++)
-            if (g == k) { cnt_g = cnt[k]; id_g = id[k]; rc_g = rc[k]; ex_g = excl[k]; }
+            if (g == k) { cnt_g = cnt[k]; id_g = id[k]; rc_g = rc[k]; ex_g = excl[k]; sp2_g = sp2[k]; }
         const uint64_t off64 = wave_off + ex_g;   // exclusive prefix of this Gaussian
         // the group's output range [grp_begin, grp_end); positions at or beyond the capacity are dropped
         const uint64_t grp_begin64 = (uint64_t)__shfl((unsigned long long)off64, 0, 64);
@@ -248,6 +263,12 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
             s_off[w][jslot] = (uint32_t)(off64 - grp_begin64);
             s_id[w][jslot] = id_g;
             s_rect[w][jslot] = rc_g;
+            s_sp2[w][jslot] = sp2_g;
+            if (id_g & SPANS_FLAG) {   // running column counts of the rows, one byte each: slot -> row without walking the rows
+                const uint32_t a4 = (rc_g.y >> 4) & 0x0F0F0F0Fu, b4 = (sp2_g >> 4) & 0x0F0F0F0Fu;
+                const uint32_t pa = a4 * 0x01010101u;
+                s_pre[w][jslot] = make_uint2(pa, b4 * 0x01010101u + (pa >> 24) * 0x01010101u);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t my_start = lane < n_nz ? s_off[w][lane] : 0xFFFFFFFFu;   // first slot of the lane-th emitting Gaussian
@@ -267,13 +288,29 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
             const uint32_t rel = c + lane;
             if (rel < range) {
                 const uint2 r = s_rect[w][owner];
-                const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16, maxx = r.y & 0xFFFFu;
-                const uint32_t width = maxx - minx;
+                const uint32_t oid = s_id[w][owner];
+                const uint32_t minx = r.x & 0xFFFFu, miny = r.x >> 16;
                 const uint32_t t = rel - s_off[w][owner];
-                const uint32_t row = t / width, col = t - row * width;
+                uint32_t row, col;
+                if (oid & SPANS_FLAG) {
+                    // t-th tile of the row spans: the row is the number of running counts <= t (a byte-wise compare: count byte
+                    // + 127 - t has its top bit set exactly when the count exceeds t; no carries, the counts are <= 120)
+                    const uint2 pre = s_pre[w][owner];
+                    const uint32_t tt = (127u - t) * 0x01010101u;
+                    const uint32_t xa = (pre.x + tt) & 0x80808080u, xb = (pre.y + tt) & 0x80808080u;
+                    row = 8u - (uint32_t)__popc(xa) - (uint32_t)__popc(xb);
+                    const uint32_t rp = row - 1u;                                     // (row 0: nothing before it)
+                    const uint32_t before = row == 0u ? 0u : (((rp < 4u ? pre.x : pre.y) >> (8u * (rp & 3u))) & 0xFFu);
+                    const uint32_t byte = ((row < 4u ? r.y : s_sp2[w][owner]) >> (8u * (row & 3u))) & 0xFFu;
+                    col = (byte & 15u) + (t - before);
+                } else {
+                    const uint32_t width = (r.y & 0xFFFFu) - minx;
+                    row = t / width;
+                    col = t - row * width;
+                }
                 const uint32_t p = grp_begin + rel;
                 keys[p] = (KeyT)((miny + row) * a.gridx + (minx + col));
-                vals[p] = s_id[w][owner];
+                vals[p] = oid & ~SPANS_FLAG;
             }
         }
     }

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 
         int radius_out = 0;
         uint32_t tiles = 0, etiles = 0, key = 0xFFFFFFFFu, cmask = 0;
-        uint2 rect = make_uint2(0, 0);
+        uint2 rect = make_uint2(0, 0), spans = make_uint2(0, 0);
+        bool spans_valid = false;
         Splat s;
         s.q0 = make_float4(0, 0, 0, 0);
         s.q1 = make_float4(0, 0, 0, 0);
@@ -205,7 +206,11 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                     // (tile_cull.hpp); `tiles`, the reference's count, still goes into tiles_touched and num_rendered
                     etiles = a.reference_lists ? ntiles
                                                : clip_rect_to_footprint(px, py, cov_x, cov_y, cov_z, det, conic_x, conic_y, conic_z,
+#ifdef GSR_NO_SPANS   // (A/B builds: bounding-box clipping only)
                                                                         opacity, r, rect, a.gridx, a.gridy);
+#else
+                                                                        opacity, r, rect, a.gridx, a.gridy, &spans, &spans_valid);
+#endif
                     s.q0 = make_float4(px, py, conic_x, conic_y);
                     s.q1 = make_float4(conic_z, opacity, rgb.x, rgb.y);
                     s.q2 = make_float4(rgb.z, p_view.z, 0.f, 0.f);
@@ -218,8 +223,12 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
         at_view(a.dkey, a.g_stride, vw)[idx] = key;
         // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
         // Gaussian; the whole 64-B line is written here
-        // (rectangle emitted, pairs emitted, pairs of the reference's rectangle)
-        const float4 q3 = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(etiles), __uint_as_float(tiles));
+        // what the emission needs (binning.hip emit_info): (first tile, last tile + 1, pairs emitted, pairs of the reference's
+        // rectangle), or with row spans (first tile, spans of rows 0-3, spans of rows 4-7, reference pairs | SPANS_FLAG)
+        const float4 q3 = spans_valid ? make_float4(__uint_as_float(rect.x), __uint_as_float(spans.x), __uint_as_float(spans.y),
+                                                    __uint_as_float(tiles | SPANS_FLAG))
+                                      : make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(etiles),
+                                                    __uint_as_float(tiles));
         const int wave_first = idx - (int)(threadIdx.x & 63);
         const bool full_wave = wave_first + 64 <= a.P;   // wave-uniform
         if (full_wave) {

@@ -78,10 +78,24 @@ __device__ __forceinline__ bool may_touch_8x8(float mx, float my, float A, float
 // hence |dx| <= sqrt(2 (tau + E) / (1 - eta) Sxx), widened by 1e-5 relative + 0.02 px for the square root and the products.
 // Anything that is not provably an ellipse (NaN, det <= 0, eta too large) keeps the reference's rectangle.
 // rect = (minx | miny << 16, maxx | maxy << 16) in tiles; returns the number of tiles left (0: the Gaussian emits nothing).
+//
+// Row spans.  Inside the clipped rectangle the ellipse still misses tiles -- the corners of a round footprint, most of the box of
+// a thin diagonal one (a tenth of the pairs the box keeps on the benchmark cloud).  For a rectangle of at most SPAN_ROWS tile rows
+// and 15 columns, `spans` receives one byte per tile row: first column (relative to minx) in the low nibble, number of columns
+// in the high one.  A tile row is the strip of pixel rows y0..y0+15, i.e. dy = mean.y - y in [d0, d1]; for a given dy the ellipse
+// d^T Sigma^-1 d <= k holds dx in m(dy) +- w(dy), m = (Sxy / Syy) dy, w^2 = (Sxx - Sxy^2 / Syy) (k - dy^2 / Syy), so the strip's
+// pixels lie in [px - max(m + w), px + max(-m + w)]: each maximum of a concave function over [d0, d1], attained at the ellipse's
+// leftmost / rightmost point if its dy lies in the strip, else at one of the strip's ends.  Same k (rounding allowances E, eta
+// inside); the cancellation in w^2 is covered by 4e-7 hx^2 under the root, the rest by 0.03 px + 1e-4 hx on the interval.
+// *spans_valid = false: rectangle too large for the encoding (or not clipped at all): every tile of rect is emitted.
+constexpr uint32_t SPAN_ROWS = 8;
+constexpr uint32_t SPANS_FLAG = 0x80000000u;   // in the fourth word of Splat::q3 (reference pair counts are < 2^27: api.hip check_params)
 __device__ __forceinline__ uint32_t clip_rect_to_footprint(float px, float py, float sxx, float sxy, float syy, float det,
                                                             float A, float B, float C, float o, float r, uint2& rect,
-                                                            uint32_t gridx, uint32_t gridy)
+                                                            uint32_t gridx, uint32_t gridy, uint2* spans = nullptr,
+                                                            bool* spans_valid = nullptr)
 {
+    if (spans_valid) *spans_valid = false;
     uint32_t minx = rect.x & 0xFFFFu, miny = rect.x >> 16, maxx = rect.y & 0xFFFFu, maxy = rect.y >> 16;
     const uint32_t full = (maxx - minx) * (maxy - miny);
     if (o < 1.0f / 255.0f) return 0u;      // alpha = o exp(power <= 0) <= o < 1/255 at every pixel (entries with power > 0 are skipped)
@@ -111,7 +125,48 @@ __device__ __forceinline__ uint32_t clip_rect_to_footprint(float px, float py, f
     maxy = maxy < cy1 ? maxy : cy1;
     if (maxx <= minx || maxy <= miny) return 0u;
     rect = make_uint2(minx | (miny << 16), maxx | (maxy << 16));
-    return (maxx - minx) * (maxy - miny);
+    const uint32_t w = maxx - minx, h = maxy - miny;
+    if (spans == nullptr || h > SPAN_ROWS || w > 15u) return w * h;
+    // ---- row spans
+    const float inv_syy = 1.0f / syy;
+    const float slope = sxy * inv_syy;                       // m(dy) = slope * dy
+    const float v = fmaxf(sxx - sxy * slope, 0.f);           // Sxx - Sxy^2 / Syy (conditional variance of dx)
+    const float hx_raw = sqrtf(k * sxx), hy_raw = sqrtf(k * syy);
+    const float root_pad = 4.0e-7f * (k * sxx);              // cancellation in v and in k - dy^2 / Syy, both <~ 1e-7 hx^2 in w^2
+    const float pad = 0.03f + 1.0e-4f * hx_raw;
+    const float dstar = hx_raw * sxy / sxx;                  // dy of the ellipse's leftmost point (dx = +hx); rightmost: -dstar
+    if (!(hx_raw >= 0.f && hy_raw >= 0.f && v == v && dstar == dstar)) return w * h;
+    uint32_t lo = 0u, hi = 0u, total = 0u;
+    // The strips are taken half a pixel wider than their pixel rows, [16 j - 0.5, 16 j + 15.5], so that consecutive tile rows share
+    // a boundary and its square root: h + 1 evaluations of (m, w) for h rows.  A boundary beyond the ellipse's own extent in y is
+    // pulled back to it (w = 0 there: the ellipse's top / bottom point).
+    const float hyc = hy_raw + 0.02f;
+    float d_raw = py - ((float)(miny * 16u) - 0.5f);                                    // dy at the upper boundary of row 0
+    float d_hi = fminf(fmaxf(d_raw, -hyc), hyc);
+    float w_b = __builtin_amdgcn_sqrtf(v * fmaxf(k - d_hi * d_hi * inv_syy, 0.f) + root_pad);
+    float er_hi = -slope * d_hi + w_b, el_hi = slope * d_hi + w_b;                      // (pixel x - px) and (px - pixel x) there
+    const int iminx = (int)minx, imaxx = (int)maxx;
+    for (uint32_t row = 0; row < h; row++) {
+        d_raw -= 16.0f;                                                                 // the next boundary: 16 pixel rows further down
+        const float d_lo = fminf(fmaxf(d_raw, -hyc), hyc);
+        const float w_n = __builtin_amdgcn_sqrtf(v * fmaxf(k - d_lo * d_lo * inv_syy, 0.f) + root_pad);
+        const float er_lo = -slope * d_lo + w_n, el_lo = slope * d_lo + w_n;
+        float right = fmaxf(er_hi, er_lo), left = fmaxf(el_hi, el_lo);
+        if (-dstar >= d_lo - 0.05f && -dstar <= d_hi + 0.05f) right = fmaxf(right, hx_raw);
+        if (dstar >= d_lo - 0.05f && dstar <= d_hi + 0.05f) left = fmaxf(left, hx_raw);
+        const float xl = fminf(fmaxf(ceilf(px - (left + pad)), -lim), lim), xr = fminf(fmaxf(floorf(px + (right + pad)), -lim), lim);
+        if (!(xl == xl && xr == xr)) return w * h;           // NaN: no row clipping
+        const int ta = (int)xl >> 4, tb = ((int)xr >> 4) + 1;        // (arithmetic shift = floor(x / 16), also below zero)
+        const int ca = ta < iminx ? iminx : (ta > imaxx ? imaxx : ta), cb = tb < iminx ? iminx : (tb > imaxx ? imaxx : tb);
+        const uint32_t count = cb > ca ? (uint32_t)(cb - ca) : 0u, first = cb > ca ? (uint32_t)(ca - iminx) : 0u;
+        const uint32_t byte = first | (count << 4);
+        if (row < 4u) lo |= byte << (8u * row); else hi |= byte << (8u * (row - 4u));
+        total += count;
+        d_hi = d_lo; er_hi = er_lo; el_hi = el_lo;
+    }
+    *spans = make_uint2(lo, hi);
+    *spans_valid = true;
+    return total;
 }
 
 // Bounding rectangle, in lane coordinates (x = lane & 7, y = lane >> 3), of the lanes set in a ballot of an 8x8
