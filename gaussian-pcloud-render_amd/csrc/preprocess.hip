@@ -95,10 +95,9 @@ struct PreArgs {
 
 // DEG = active SH degree (template parameter: the 3 (DEG+1)^2 coefficients a Gaussian needs are read ONCE into registers and
 // reused for every view of the batch -- re-reading them per view pulled the 156-B-stride SH rows from HBM five times over)
+// (135 registers at degree 1 = three waves per SIMD; forcing four -- amdgpu_waves_per_eu(4, 4), 128 registers -- spills: 0.029 ->
+// 0.031 ms per view at 12 views per call, 0.067 -> 0.187 at one)
 template <int DEG>
-#ifdef GSR_PRE_WAVES
-__attribute__((amdgpu_waves_per_eu(GSR_PRE_WAVES, GSR_PRE_WAVES)))
-#endif
 __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 {
     // A thread owns one Gaussian for a.vpt consecutive views of the batch: the inputs (mean, scale / rotation -> 3D

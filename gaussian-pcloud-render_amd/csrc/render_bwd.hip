@@ -749,7 +749,10 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     // the number of items is only known on the device: every view gets the same number of workgroup quartets, enough in
     // total to fill the chip's wave slots several times over, and they walk the view's item list with a stride
     int64_t groups = div_up(a.num_tiles, 8);
-    const int64_t fill = div_up(4096, B.V);        // 4096 groups x 32 single-wave workgroups = 25 per wave slot (measured: 1280 / 2048 / 2560 / 4096 / 8192 groups -> 0.216 / 0.213 / 0.211 / 0.210 / 0.221 ms per view)
+#ifndef GSR_BWD_FILL
+#define GSR_BWD_FILL 4096
+#endif
+    const int64_t fill = div_up(GSR_BWD_FILL, B.V);        // 4096 groups x 32 single-wave workgroups = 25 per wave slot (measured: 1280 / 2048 / 2560 / 4096 / 8192 groups -> 0.216 / 0.213 / 0.211 / 0.210 / 0.221 ms per view)
     if (groups > fill) groups = fill;
     if (groups < 8) groups = 8;
     hipLaunchKernelGGL(k_render_backward, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
