@@ -156,7 +156,9 @@ int gsr_forward_stage2(const gsr_params* p, void* geom, size_t geom_bytes, void*
 int gsr_forward_recolor(const gsr_params* p, int V, int colors_per_view, void* geom, size_t geom_bytes, const void* binning,
                         size_t binning_bytes, void* image, size_t image_bytes, float* out_color, gsr_stream_t stream);
 
-/* Backward of a batch (rasterize_points.cu:117-196 / Rasterizer::backward rasterizer.h:61-90).  dL_dpix is [V,3,H,W]; the
+/* Backward of a batch (rasterize_points.cu:117-196 / Rasterizer::backward rasterizer.h:61-90), on the arenas of ONE forward call and with
+ * that call's V (the arenas' internal layout -- per-view strides, the length of the list slices whose boundary states the forward
+ * saved -- follows from V; a forward batch cannot be split into several backward calls).  dL_dpix is [V,3,H,W]; the
  * per-Gaussian gradients are SUMMED over the V views (what autograd does with the reference's per-view calls on a shared
  * cloud).  Every output is written for every Gaussian (zeros where it is invisible; all M rows of dL_dsh), so nothing has
  * to be cleared by the caller -- the reference zero-fills nine tensors per call (rasterize_points.cu:151-159) -- except
