@@ -694,6 +694,6 @@ int gsr_last_list_pairs(int64_t* out, int V)
 }
 
 const char* gsr_last_error(void) { return gsr::g_err; }
-const char* gsr_version(void) { return "gsr-hip 0.2 (gfx950)"; }
+const char* gsr_version(void) { return "gsr-hip 0.3 (gfx950)"; }
 
 }  // extern "C"
