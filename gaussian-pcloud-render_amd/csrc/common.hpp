@@ -65,7 +65,9 @@ __host__ __device__ __forceinline__ T* at_view(T* p, size_t stride_bytes, uint32
 // Per-Gaussian packed splat record: what the render kernels gather per list entry.  Padded to one 64-B cache line, so a
 // gather touches exactly one line (a 48-B record straddles two half of the time) and preprocess writes whole lines.
 //   q0 = (x, y, conic.x, conic.y)   q1 = (conic.z, opacity, r, g)   q2 = (b, depth, 0, 0)
-//   q3 = (tile rect min: x | y << 16, tile rect max: x | y << 16, tiles touched, -) as raw bits, for the pair emission
+//   q3 = raw bits for the pair emission: (first tile x | y << 16, last tile + 1, pairs emitted, pairs of the reference's rectangle), or --
+//        rectangles of at most 8 x 15 tiles after footprint clipping -- (first tile, row spans of rows 0-3, of rows 4-7, reference
+//        pairs | SPANS_FLAG): one byte per tile row, first column in the low nibble, columns in the high one (tile_cull.hpp)
 struct __attribute__((aligned(64))) Splat {
     float4 q0, q1, q2, q3;
 };
