@@ -14,7 +14,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")   # (GSR_LIB: another build of the same ABI, for A/B runs)
 
 _fp = C.c_void_p
 
