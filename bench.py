@@ -62,6 +62,9 @@ STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_ren
                 "preprocess_backward": "k_preprocess_backward<1>", "duplicate": "k_duplicate<unsigned short>"}
 
 
+GC_RECOVER_S = 0.15   # untimed load between the garbage collection and the first timed block (seconds)
+
+
 def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes, views_per_call=1):
     """Minimum HBM bytes each stage has to move PER FRAME when `views_per_call` views of one cloud travel in one submission.
     Render / preprocess figures are SURVEY.md 8(d)'s per-view formulas with what a batched launch shares counted once per batch:
@@ -411,8 +414,22 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    run_steps(0, max(args.steps, VPC))      # the collection left the GPU idle for tens of ms: back to the clock under load
-    warm_steps += max(args.steps, VPC)
+    # the collection left the GPU idle for tens of ms and the clock governor let go: one 20-step block (10 ms) does not bring the
+    # clock back -- the first timed block of a --steps 20 run read 2 290-2 370 MHz, the second 2 380-2 420, the rest 2 430 -- so
+    # untimed blocks run until GC_RECOVER_S of load have passed (rank 0's clock decides, like the warm-up above)
+    t_g = time.perf_counter()
+    while True:
+        run_steps(0, max(args.steps, VPC))
+        warm_steps += max(args.steps, VPC)
+        torch.cuda.synchronize()
+        more[0] = int(time.perf_counter() - t_g < GC_RECOVER_S)
+        if use_dist:
+            mt = more.to("cpu" if host_collectives else dev)
+            dist.broadcast(mt, src=0)
+            more.copy_(mt)
+        if not int(more[0]):
+            break
+    warm_seconds = time.perf_counter() - t_w
     fence()
     block_dt = []
     block_base = []          # one event per timed block, recorded on the caller's stream when the block starts
@@ -705,7 +722,9 @@ def main():
             "warmup": args.warmup,
             "warmup_effective": {"steps": int(warm_steps), "seconds": round(warm_seconds, 3),
                                  "note": "--warmup steps, allocator / stream priming, then whole blocks until --warmup-seconds "
-                                         "(%.2f) had passed; all untimed" % args.warmup_seconds},
+                                         "(%.2f) had passed, the garbage collection, then whole blocks for %.2f s more (the collection "
+                                         "idles the GPU for tens of ms and the clock needs ~50 ms of load to come back); all untimed"
+                                         % (args.warmup_seconds, GC_RECOVER_S)},
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "python_gc": "collected before, disabled inside the timed region (like timeit)",
             "overlap_of_consecutive_calls": {"on": bool(_native._OVERLAP_ON), "calls_overlapped_in_timed_region": overlap_timed,
