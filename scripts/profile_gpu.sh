@@ -44,6 +44,8 @@ python $PWD/bench.py --config 4 --steps 16 --warmup 8 --no-cpu-baseline --no-per
 python $PWD/bench.py --config 3 --steps 16 --warmup 8 --no-cpu-baseline --no-per-view > $OUT/bench_config3.json 2> $OUT/bench_config3.err
 tail -c 300 $OUT/bench_config1.err $OUT/bench_config4.err $OUT/bench_config3.err
 fi
+# the round driver's command line (20-step blocks: one 12-view and one 8-view submission each)
+python $PWD/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_shape.json 2> $OUT/bench_driver_shape.err
 python $PWD/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt
 # keep the merge small: drop the raw per-dispatch traces, keep stats + counter CSVs

@@ -17,6 +17,12 @@ if os.path.exists(os.path.join(src, "timeline.txt")):
     shutil.copy(os.path.join(src, "timeline.txt"), os.path.join(dst, "%s_timeline.txt" % tag))
 if os.path.exists(os.path.join(src, "fetch_calibration.txt")):
     shutil.copy(os.path.join(src, "fetch_calibration.txt"), os.path.join(dst, "%s_fetch_calibration.txt" % tag))
+for extra in ("bench_driver_shape", "bench_config1", "bench_config3", "bench_config4"):
+    f = os.path.join(src, extra + ".json")
+    if os.path.exists(f):
+        lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(dst, "%s_%s.json" % (tag, extra)), "w"), indent=1)
 bench = json.loads([l for l in open(os.path.join(src, "bench.json")).read().splitlines() if l.startswith("{")][-1])
 json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
 wl = bench["config"]["workload"]
