@@ -113,10 +113,14 @@ struct GeomView {
 // concurrently; the forward pass leaves the per-pixel state (T, accumulated colour) at every chunk boundary it crosses.
 // The chunk length depends on the views per submission (both halves of a frame see the same V, so both derive the same length):
 // a single view's backward launch ends on its longest serial walks and wants them short -- 0.267 / 0.236 / 0.229 ms per view with
-// chunks of 1024 / 512 / 256 entries, against 0.012 / 0.016 / 0.019 ms for the item list -- while a 12-view launch hides them behind
-// the other views' work and pays for the extra items and boundary states instead (0.207 / 0.215 ms per view with 1024 / 512).
+// chunks of 1024 / 512 / 256 entries, against 0.012 / 0.016 / 0.019 ms for the item list -- while already two views hide each
+// other's walks and a batch pays for the extra items and boundary states instead (ms per view with 1024 / 512 entries: 2 views 0.228 /
+// 0.227, 3: 0.220 / 0.217, 4: 0.217 / 0.233, 6: 0.215 / 0.211, 8: 0.215 / 0.215, 12: 0.207 / 0.215; scripts/debug/chunk_v_exp.sh).
 constexpr int BWD_CHUNK_SHIFT_MIN = 9;     // the binning arena's boundary-state area is carved for this length
-__host__ __device__ inline int bwd_chunk_shift(int V) { return V >= 8 ? 10 : 9; }
+#ifndef GSR_CHUNK_V
+#define GSR_CHUNK_V 2     // views per submission from which the slices are 1024 entries long
+#endif
+__host__ __device__ inline int bwd_chunk_shift(int V) { return V >= GSR_CHUNK_V ? 10 : 9; }
 constexpr int BWD_MAX_CHUNKS = 32;   // per tile; the last one takes whatever is left
 constexpr int BWD_TILE_BITS = 27;    // item = tile | chunk << 27 (check_params limits images to 2^27 tiles)
 
