@@ -62,7 +62,7 @@ struct DupArgs {
     uint32_t gridx;
     const uint32_t* order[2];        // ids in depth order: the depth sort's ping-pong buffers ...
     const uint32_t* sortctl;         // ... and how many of its passes ran this frame (an odd count leaves the result in buffer 1)
-    const Splat* splat;              // q3 = (rect.x, rect.y, tiles touched, -) as written by k_preprocess
+    const Splat* splat;              // q3: what the Gaussian emits + the reference's pair count, as written by k_preprocess (common.hpp)
     uint64_t* dup_status;            // [nblk] zeroed before the launch; pair count + 1 once a workgroup has published
     uint64_t* counters;
     size_t g_stride;
