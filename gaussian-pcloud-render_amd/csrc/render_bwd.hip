@@ -34,7 +34,7 @@ namespace gsr {
 constexpr int BGRP = 4;  // entries evaluated per inner-loop trip
 
 #ifndef GSR_BWD_DIV
-#define GSR_BWD_DIV 1   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
+#define GSR_BWD_DIV 0   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
 #endif
 #ifndef GSR_BWD_NOFMA
 #define GSR_BWD_NOFMA 0
@@ -166,7 +166,7 @@ __device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am
 }
 
 #ifdef GSR_BWD_EMUL
-// DIAGNOSTIC build only (scripts/gpu_session_r4b.sh): the same contraction as mm_contract by plain arithmetic, pixels in
+// DIAGNOSTIC build only (scripts/leases/gpu_session_r4b.sh): the same contraction as mm_contract by plain arithmetic, pixels in
 // raster order -- GSR_BWD_EMUL = 1: float fmaf chain, 2: double -- to tell the matrix cores' summation apart from the
 // moment shift when the accuracy of the sums is in question.  dpx: [3][64] dL_dpixel of the item, raster order.
 __device__ __forceinline__ f32x4 mm_contract_emul(const float* mrow, const float* dpx, uint32_t lane)

@@ -809,6 +809,130 @@ void orc_render_backward_fp64(const orc_inputs *in, const orc_state *st, const f
     free(rows);
 }
 
+/* MODEL of an alternative float32 formulation of the per-(pixel, entry) weights (not a restatement of reference arithmetic; used by
+ * scripts/bwd_formulations.py to price a formulation's rounding against orc_render_backward_fp64 before it is built on the GPU).
+ * The nine partial derivatives are formed from (T, dL_dalpha) exactly like render_tile_backward (float terms, double sums);
+ * what differs is how T and dL_dalpha are obtained:
+ *   mode 0: the reference's back-to-front walk (T = T / (1 - alpha), accum_rec recurrence) -- equals render_tile_backward
+ *   mode 1: FRONT-TO-BACK: T by the forward's own multiply chain (exact), S = sum_{j<=i} w_j d_j (d = c . dL_dpixel, w = alpha T)
+ *           accumulated with fmaf, dL_dalpha = T d - (S_tot - S) * (1 / (1 - alpha)), S_tot = C_final . dL_dpixel + T_final bg . dL_dpixel
+ *           with C_final the float forward's accumulated colour.   */
+static void render_tile_backward_model(const orc_inputs *in, const orc_state *st, const float *colors, const float *dL_dpix,
+                                       int tx, int ty, double *out9, double *loc, int mode)
+{
+    const int W = in->W, H = in->H;
+    const uint32_t r0 = st->ranges[2 * (ty * st->gridx + tx)], r1 = st->ranges[2 * (ty * st->gridx + tx) + 1];
+    const int toDo = (int)(r1 - r0);
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    if (toDo <= 0) return;
+    memset(loc, 0, (size_t)toDo * 9 * sizeof(double));
+    for (int ly = 0; ly < BLOCK_Y; ly++)
+        for (int lx = 0; lx < BLOCK_X; lx++) {
+            const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+            if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+            const uint32_t pix_id = W * py + px;
+            const float pixf_x = (float)px, pixf_y = (float)py;
+            const float T_final = st->final_T[pix_id];
+            const int last = (int)st->n_contrib[pix_id] < toDo ? (int)st->n_contrib[pix_id] : toDo;
+            float dpx[3], bg_dot = 0;
+            for (int i = 0; i < 3; i++) dpx[i] = dL_dpix[(size_t)i * H * W + pix_id];
+            for (int i = 0; i < 3; i++) bg_dot += in->bg[i] * dpx[i];
+            /* forward colour of the pixel as the float forward accumulates it */
+            float Cf[3] = {0, 0, 0}, Tf = 1.f;
+            for (int k = 0; k < last; k++) {
+                const uint32_t id = st->vals[r0 + k];
+                const float *co = st->conic_opacity + 4 * id;
+                const float dx = st->means2D[2 * id] - pixf_x, dy = st->means2D[2 * id + 1] - pixf_y;
+                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf_cuda(0.99f, co[3] * expf(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                for (int ch = 0; ch < 3; ch++) Cf[ch] += colors[id * 3 + ch] * alpha * Tf;
+                Tf = Tf * (1 - alpha);
+            }
+            const float S_tot = fmaf(T_final, bg_dot, fmaf(Cf[2], dpx[2], fmaf(Cf[1], dpx[1], Cf[0] * dpx[0])));
+            float T = mode == 0 ? T_final : 1.f, S = 0.f;
+            float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0;
+            for (int j = 0; j < last; j++) {
+                const int k = mode == 0 ? last - 1 - j : j;
+                const uint32_t id = st->vals[r0 + k];
+                double *row = loc + (size_t)k * 9;
+                const float *co = st->conic_opacity + 4 * id;
+                const float dx = st->means2D[2 * id] - pixf_x, dy = st->means2D[2 * id + 1] - pixf_y;
+                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.0f) continue;
+                const float G = expf(power);
+                const float alpha = fminf_cuda(0.99f, co[3] * G);
+                if (alpha < 1.0f / 255.0f) continue;
+                float dL_dalpha, Ti;
+                if (mode == 0) {
+                    T = T / (1.f - alpha);
+                    Ti = T;
+                    dL_dalpha = 0.f;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[id * 3 + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                } else {
+                    const float om = 1.f - alpha, rcp = 1.f / om;
+                    const float d = fmaf(colors[id * 3 + 2], dpx[2], fmaf(colors[id * 3 + 1], dpx[1], colors[id * 3] * dpx[0]));
+                    Ti = T;
+                    S = fmaf(alpha * T, d, S);
+                    dL_dalpha = fmaf(-(S_tot - S), rcp, T * d);
+                    T = T * om;
+                }
+                const float dchannel_dcolor = alpha * Ti;
+                for (int ch = 0; ch < 3; ch++) row[6 + ch] += (double)(dchannel_dcolor * dpx[ch]);
+                const float dL_dG = co[3] * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co[0] - gdy * co[1], dG_ddely = -gdy * co[2] - gdx * co[1];
+                row[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                row[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                row[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                row[3] += (double)(-0.5f * gdx * dy * dL_dG);
+                row[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                row[5] += (double)(G * dL_dalpha);
+            }
+        }
+    for (int k = 0; k < toDo; k++) {
+        const double *row = loc + (size_t)k * 9;
+        double *dst = out9 + (size_t)st->vals[r0 + k] * 9;
+        for (int c = 0; c < 9; c++)
+            if (row[c] != 0.0) {
+#pragma omp atomic
+                dst[c] += row[c];
+            }
+    }
+}
+
+/* see render_tile_backward_model; out9 [P][9] zero-filled by the caller, rows as orc_render_backward_fp64 */
+void orc_render_backward_model(const orc_inputs *in, const orc_state *st, const float *dL_dpix, double *out9, int mode, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (in->P == 0) return;
+    const float *color_ptr = in->colors_precomp ? in->colors_precomp : st->rgb;
+    const int ntiles = st->gridx * st->gridy;
+    size_t longest = 1;
+    for (int t = 0; t < ntiles; t++) {
+        const size_t len = (size_t)(st->ranges[2 * t + 1] - st->ranges[2 * t]);
+        if (len > longest) longest = len;
+    }
+    double *rows = (double *)malloc(sizeof(double) * 9 * longest * (size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
+    {
+        double *loc = rows + (size_t)omp_get_thread_num() * 9 * longest;
+#pragma omp for schedule(dynamic, 4)
+        for (int t = 0; t < ntiles; t++)
+            render_tile_backward_model(in, st, color_ptr, dL_dpix, t % st->gridx, t / st->gridx, out9, loc, mode);
+    }
+    free(rows);
+}
+
 /* CR/backward.cu:144-274 (computeCov2DCUDA) */
 static void cov2d_backward_one(const orc_inputs *in, const orc_state *st, const float *cov3Ds, float h_x, float h_y,
                                const float *dL_dconics, float *dL_dmeans, float *dL_dcov, int idx)

@@ -98,6 +98,9 @@ void orc_backward(const orc_inputs *in, const orc_state *st, const float *dL_dpi
  * colour rgb) with every per-(pixel, entry) term evaluated in double from the float render inputs, following the float
  * forward's decisions.  out9 [P][9] must be zero-filled. */
 void orc_render_backward_fp64(const orc_inputs *in, const orc_state *st, const float *dL_dpix, double *out9, int nthreads);
+/* float32 MODEL of a formulation of the per-(pixel, entry) weights, double sums (mode 0: the reference's back-to-front walk,
+ * 1: front-to-back with T by the forward's multiply chain); prices a formulation's rounding against the function above */
+void orc_render_backward_model(const orc_inputs *in, const orc_state *st, const float *dL_dpix, double *out9, int mode, int nthreads);
 
 /* CR/rasterizer_impl.cu:54-66,141-153 */
 void orc_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
