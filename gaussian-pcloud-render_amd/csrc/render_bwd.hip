@@ -34,7 +34,7 @@ namespace gsr {
 constexpr int BGRP = 4;  // entries evaluated per inner-loop trip
 
 #ifndef GSR_BWD_DIV
-#define GSR_BWD_DIV 0   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
+#define GSR_BWD_DIV 1   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
 #endif
 #ifndef GSR_BWD_NOFMA
 #define GSR_BWD_NOFMA 0

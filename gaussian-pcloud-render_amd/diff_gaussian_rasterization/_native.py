@@ -217,18 +217,22 @@ def reset_capacity_hints():
 #     now -- exactly the unoverlapped order.
 # Tensors are remembered by weak reference (no lifetime is extended; a recycled address can not impersonate an old tensor).
 # What the version counter does not see -- `t.data.copy_(...)`, a foreign kernel writing through `data_ptr()` -- is not seen here
-# either: autograd's own in-place checks have the same blind spot.  GSR_OVERLAP=0 / set_overlap(False) restores plain
-# in-stream execution.  All outputs and arenas are allocated on the side stream and handed to the caller's stream with
+# either: autograd's own in-place checks have the same blind spot (a swapped storage, `t.data = other`, IS seen: the record
+# holds data_ptr / offset / shape / strides).  Off by default (below); when on, set_overlap(False) restores plain in-stream execution.  All outputs and arenas are allocated on the side stream and handed to the caller's stream with
 # record_stream, so torch's caching allocator never recycles them under a kernel that still runs.
 import weakref as _weakref
 
+# OPT-IN since round 5 (GSR_OVERLAP=1 or set_overlap(True)): what the overlap is worth depends on which hardware queues the runtime
+# binds the side streams to at their first launch -- 1 250-1 360 frames/s in most processes, 1 010-1 160 in some, in-order 985 --
+# which a process can neither see nor choose, and the reference's literal caller (fresh settings tensors per call,
+# simple_raw_render.py:260-263) never qualifies for it anyway: the default is plain stream order, the same in every process.
 # Each side stream wants a hardware queue of its own (the ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES queues, default 4,
-# and streams that share a queue serialise); the variable is only read when HIP starts, so it can only be defaulted here if the
-# process has not touched the GPU yet.
-if not torch.cuda.is_initialized():
+# and streams that share a queue serialise); the variable is read when HIP starts and changes the stream-to-queue mapping of the
+# whole process, so the library only touches it when asked to (GSR_SET_HW_QUEUES=1, before the process first uses the GPU).
+if os.environ.get("GSR_SET_HW_QUEUES", "0") == "1" and not torch.cuda.is_initialized():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-_OVERLAP_ON = os.environ.get("GSR_OVERLAP", "1") != "0"
+_OVERLAP_ON = os.environ.get("GSR_OVERLAP", "0") == "1"
 _OVERLAP_STREAMS = int(os.environ.get("GSR_OVERLAP_STREAMS", "3"))
 _OVERLAP_PRIORITY = int(os.environ.get("GSR_OVERLAP_PRIORITY", "-1"))    # -1: side streams above the caller's stream
 OVERLAP_MAX_VIEWS = 3
@@ -254,8 +258,14 @@ class _OverlapState:
         # to follow what is in flight at the first launch), so the streams are taken as they come.
         self.streams = [torch.cuda.Stream(device=device, priority=_OVERLAP_PRIORITY) for _ in range(_OVERLAP_STREAMS)]
         self.turn = 0
-        self.seen = {}       # id(tensor) -> (weakref, version, event, sequence number)
+        self.seen = {}       # id(tensor) -> (weakref, version, event, sequence number, storage key)
         self.seq = 0
+
+    @staticmethod
+    def _where(t):
+        """What the tensor object points at: `param.data = other` (weight clamping, checkpoint loading, densification code) swaps
+        the storage under the same Python object WITHOUT bumping the version counter, so object identity + version is not enough."""
+        return (t.data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
 
     def input_event(self, tensors, cur):
         """The event the side stream has to wait for: the newest `first seen` event when every input is a known, unmodified
@@ -268,7 +278,7 @@ class _OverlapState:
             except RuntimeError:      # inference tensor: no version counter, never assumed unchanged
                 return self._now(cur, []), False
             rec = self.seen.get(id(t))
-            if rec is not None and rec[0]() is t and rec[1] == ver:
+            if rec is not None and rec[0]() is t and rec[1] == ver and rec[4] == self._where(t):
                 if newest is None or rec[3] > newest[3]:
                     newest = rec
             else:
@@ -285,7 +295,7 @@ class _OverlapState:
             if len(self.seen) > 512:
                 self.seen.clear()
         for t, ver in missing:
-            self.seen[id(t)] = (_weakref.ref(t), ver, ev, self.seq)
+            self.seen[id(t)] = (_weakref.ref(t), ver, ev, self.seq, self._where(t))
         return ev
 
     def next_stream(self):

@@ -19,9 +19,14 @@ def max_shard(n_views, world):
     return (n_views + world - 1) // world
 
 
+def _global_rank(group, r):
+    """torch.distributed's P2POp peers and collective roots are GLOBAL ranks; `r` counts inside `group`"""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def gather_to_root(src, bufs, dst=0, group=None, mode="collective"):
     """One frame-gather step: every rank's `src` lands in bufs[rank] on `dst` (bufs: list of world tensors shaped like src on dst,
-    None elsewhere).
+    None elsewhere).  `dst` and the indices of `bufs` are ranks WITHIN `group` (the default group: global ranks).
 
     mode "collective": torch.distributed.gather -- one RCCL collective; how it drives the links is the library's business.
     mode "p2p": the root posts one receive per peer and every peer one send, all in ONE batch_isend_irecv group
@@ -30,16 +35,16 @@ def gather_to_root(src, bufs, dst=0, group=None, mode="collective"):
         over the peers.  The fallback DESIGN.md section 8 names; same result, same call order on every rank.
     Returns the list of outstanding work handles (empty for "collective"): wait() on them before reading bufs / reusing src."""
     if mode == "collective":
-        dist.gather(src, gather_list=bufs, dst=dst, group=group)
+        dist.gather(src, gather_list=bufs, dst=_global_rank(group, dst), group=group)
         return []
     if mode != "p2p":
         raise ValueError("gather mode: 'collective' or 'p2p'")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if rank == dst:
         bufs[dst].copy_(src)
-        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst]
+        ops = [dist.P2POp(dist.irecv, bufs[r], _global_rank(group, r), group) for r in range(world) if r != dst]
     else:
-        ops = [dist.P2POp(dist.isend, src, dst, group)]
+        ops = [dist.P2POp(dist.isend, src, _global_rank(group, dst), group)]
     return dist.batch_isend_irecv(ops) if ops else []
 
 

@@ -70,7 +70,9 @@ typedef struct gsr_params {
     int prefiltered;
     int debug;
     int need_backward;     /* 0: inference call, skip the saves only gsr_backward reads (SH clamp mask,
-                              accumulated colour, per-pixel state at the 1024-entry list boundaries);
+                              accumulated colour, per-pixel state at the list-slice boundaries the backward's
+                              work items start from: every 512 entries of a tile's list in single-view
+                              submissions, every 1024 from two views per submission on);
                               gsr_backward is only valid after a forward with need_backward = 1      */
     int reference_lists;   /* 0 (default): a Gaussian emits pairs for the tiles of the reference's rectangle
                               (auxiliary.h:46-56) in which alpha can reach 1/255 -- the rectangle clipped to the

@@ -1,5 +1,6 @@
 """CPU tests of the N>1 path: view sharding + frame gather + gradient reduction with torch.distributed `gloo`,
-world_size 2 (and 3 for an uneven split), one process per rank, rendezvous on 127.0.0.1."""
+world_size 2 (and 3 for an uneven split), one process per rank, rendezvous on 127.0.0.1; an EIGHT-rank rehearsal of BASELINE
+configs[3] / [4]'s shape (8 views, one per rank; no 8-GPU node has run this code yet); a gather inside a sub-group."""
 import os
 import sys
 
@@ -76,6 +77,58 @@ def test_gather_p2p_fallback_world2_and_world3():
     drive the seven xGMI links at once) delivers what the collective delivers, even and uneven shards"""
     _run(2, 12, 29636, mode="p2p")
     _run(3, 8, 29637, mode="p2p")
+
+
+def test_eight_ranks_one_view_each_both_gather_modes():
+    """BASELINE configs[3] / [4]: 8 views dealt to 8 ranks (rank r owns view r), frames gathered on rank 0, gradients all-reduced"""
+    _run(8, 8, 29641)
+    _run(8, 8, 29642, mode="p2p")
+
+
+def test_eight_ranks_twelve_views_uneven():
+    _run(8, 12, 29643)     # the headline's 12 circle views on 8 ranks: shards of 2,2,2,2,1,1,1,1
+
+
+def _subgroup_worker(rank, world, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcrender import multiview
+    try:
+        members = [1, 2, 3]                       # global ranks of the group = group ranks 0, 1, 2 (new_group sorts them)
+        grp = dist.new_group(ranks=members)
+        ok = True
+        if rank in members:
+            me = dist.get_rank(grp)
+            ok = me == members.index(rank)
+            src = _frame(10 + me)
+            root = 1                              # GROUP rank 1 = global rank 2
+            bufs = [torch.empty_like(src) for _ in members] if me == root else None
+            for w in multiview.gather_to_root(src, bufs, dst=root, group=grp, mode=mode):
+                w.wait()
+            if me == root:
+                ok = ok and all(torch.equal(bufs[r], _frame(10 + r)) for r in range(len(members)))
+        dist.barrier()            # (the rank outside the group must not tear its connections down under the others' gather)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["collective", "p2p"])
+def test_gather_inside_a_subgroup_uses_group_ranks(mode):
+    """dst and the buffer indices count inside the group; the P2POp peers / the collective's root are translated to global ranks
+    (group ranks 0, 1, 2 = global ranks 1, 2, 3; root = group rank 1 = global rank 2; global rank 0 stays outside)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29644 if mode == "collective" else 29645
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 4, port, q, mode)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(4)]
 
 
 def test_single_process_passthrough():

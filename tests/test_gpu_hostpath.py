@@ -224,6 +224,7 @@ def test_consecutive_per_view_calls_overlap_only_when_the_inputs_are_provably_un
         torch.cuda.synchronize()
         return imgs
 
+    was_on = N._OVERLAP_ON          # (off by default since round 5: opt-in, GSR_OVERLAP=1)
     N.set_overlap(False)
     L0 = leaves()
     want = loop(L0, settings, 8)
@@ -260,6 +261,20 @@ def test_consecutive_per_view_calls_overlap_only_when_the_inputs_are_provably_un
             img, _ = GaussianRasterizer(s2)(**L0)
             assert torch.equal(img, want[k % 4])
     assert N.OVERLAP_STATS["overlapped"] == 0 and N.OVERLAP_STATS["calls"] == 6
+    # (4) a storage swapped under the same tensor object (`param.data = other`: no version bump) is seen as a new input
+    N.OVERLAP_STATS.update(calls=0, overlapped=0)
+    L3 = leaves()
+    with torch.no_grad():
+        GaussianRasterizer(settings[0])(**L3)
+        GaussianRasterizer(settings[1])(**L3)
+        assert N.OVERLAP_STATS["overlapped"] == 1
+        moved = L3["means3D"].detach() + 0.01          # produced on the caller's stream right before the call
+        ver = L3["means3D"]._version
+        L3["means3D"].data = moved
+        assert L3["means3D"]._version == ver
+        img_sw, _ = GaussianRasterizer(settings[0])(**L3)
+    assert N.OVERLAP_STATS["overlapped"] == 1 and torch.equal(img_sw, img_ref)
+    N.set_overlap(was_on)
 
 
 def test_overlap_of_consecutive_calls_survives_a_random_training_script(gpu_device):
@@ -285,6 +300,8 @@ def test_overlap_of_consecutive_calls_survives_a_random_training_script(gpu_devi
                     L[k].add_(1e-3 * torch.from_numpy(rng.standard_normal(tuple(L[k].shape)).astype(np.float32)).to(dev))
             elif what < 0.22:                    # a parameter replaced by a NEW tensor (densification does this)
                 L["rotations"] = (L["rotations"].detach() * 1.0).requires_grad_(True)
+            elif what < 0.29:                    # the STORAGE replaced under the same tensor object: no version bump (weight
+                L["opacities"].data = (L["opacities"].detach() * 0.999).clamp_(0.01, 1.0)   # clamping, checkpoint loading)
             ctx = torch.cuda.stream(other) if rng.random() < 0.2 else _Null()
             if isinstance(ctx, _Null):
                 pass
@@ -315,11 +332,13 @@ def test_overlap_of_consecutive_calls_survives_a_random_training_script(gpu_devi
         def __exit__(self, *a):
             return False
 
+    was_on = N._OVERLAP_ON
     N.set_overlap(False)
     want, gw = script(11)
     N.set_overlap(True)
     N.OVERLAP_STATS.update(calls=0, overlapped=0)
     got, gg = script(11)
+    N.set_overlap(was_on)
     assert N.OVERLAP_STATS["overlapped"] > 10, N.OVERLAP_STATS
     assert len(got) == len(want)
     for i, (a, b) in enumerate(zip(got, want)):
