@@ -362,12 +362,12 @@ int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes,
 
 int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
                                void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume,
-                               int nx, const float* extra, const float* extra_view_scale, const float* bg_extra, float* out_extra,
-                               gsr_stream_t stream)
+                               int nx, int extra_per_view, const float* extra, const float* extra_view_scale, const float* bg_extra,
+                               float* out_extra, gsr_stream_t stream)
 {
     if (nx != 4 && nx != 8) return fail(GSR_ERR_INVALID, "[gsr] extra channels come in 4 or 8 (got %d): pad with zeros", nx);
     if (!extra || !bg_extra || !out_extra) return fail(GSR_ERR_INVALID, "[gsr] an extra-channel pointer is NULL");
-    const ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra};
+    const ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra, extra_per_view ? (size_t)p->P * (size_t)nx : (size_t)0};
     return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
                         resume ? 1 : 0, (hipStream_t)stream, &X);
 }

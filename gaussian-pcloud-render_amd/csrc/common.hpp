@@ -313,10 +313,11 @@ int launch_bwd_items(const Launch& L, const Batch& B, int T, int P);
 // Extra channels composited by the forward render with the alphas of the colour pass (4 or 8 per call).
 struct ExtraChannels {
     int nx;                   // 4 or 8
-    const float* values;      // [P][nx]
+    const float* values;      // [P][nx], or [V][P][nx] with view_stride = P * nx
     const float* view_scale;  // [V][nx] or NULL
     const float* bg;          // [nx]
     float* out;               // [V][nx][H][W]
+    size_t view_stride;       // floats between consecutive views' value arrays (0: one array shared by the views)
 };
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
                           bool with_ckpt, const ExtraChannels* X = nullptr);

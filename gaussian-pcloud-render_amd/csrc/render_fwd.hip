@@ -48,7 +48,8 @@ struct RenderArgs {
     uint32_t V;                              // views in the batch
     size_t g_stride, b_stride, iv_stride;    // bytes between consecutive views' arenas
     // extra channels (k_render_forward<NX>, NX > 0): composited with the same alphas as the colour
-    const float* extra;        // [P][NX] per-Gaussian values, shared by the views
+    const float* extra;        // [P][NX] per-Gaussian values, shared by the views (extra_vstride = 0) or one array per view
+    size_t extra_vstride;      // floats between consecutive views' arrays
     const float* extra_scale;  // [V][NX] per-view factors applied to them (NULL: 1), e.g. the +-1 of view-dependent normals
     const float* bg_extra;     // [NX]
     float* out_extra;          // [V][NX][H][W]
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
     a.splat = at_view(a.splat, a.g_stride, view);
     a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
+    if (NX > 0) a.extra += (size_t)view * a.extra_vstride;
     const uint32_t tile = a.tile_order[order_slot];
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
@@ -552,10 +554,10 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     a.num_tiles = T;
     a.chunk_shift = B.chunk_shift();
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
-    a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr;
+    a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr; a.extra_vstride = 0;
     const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);
     if (X != nullptr && X->nx > 0) {
-        a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out;
+        a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out; a.extra_vstride = X->view_stride;
         if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
         else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
     } else {

@@ -61,7 +61,7 @@ def _load():
                                       C.POINTER(C.c_int64), C.c_int, _fp]
     lib.gsr_forward_batch_channels.restype = C.c_int
     lib.gsr_forward_batch_channels.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
-                                               _fp, _fp, C.POINTER(C.c_int64), C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]
+                                               _fp, _fp, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]
     lib.gsr_forward_stage1.restype = C.c_int
     lib.gsr_forward_stage1.argtypes = [C.POINTER(GsrParams), _fp, C.c_size_t, _fp, C.c_size_t, _fp,
                                        C.POINTER(C.c_int64), _fp]
@@ -351,8 +351,9 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     """V views of one cloud in one submission (C ABI gsr_forward_batch): viewmatrices / projmatrices [V,4,4] (transposed like
     the reference's settings), camposs [V,3].  Returns (num_rendered list[V], out_color [V,3,H,W], radii [V,P],
     geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity.
-    extra = (values [P,nx], view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the render also composites those channels
-    with the colour's alphas (gsr_forward_batch_channels) and the result gains a 7th element, out_extra [V,nx,H,W]."""
+    extra = (values [P,nx] shared by the views or [V,P,nx] per view, view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the
+    render also composites those channels with the colour's alphas (gsr_forward_batch_channels) and the result gains a 7th
+    element, out_extra [V,nx,H,W]."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = means3D.device
@@ -366,9 +367,10 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     xv = xs = xb = None
     if extra is not None:
         xv, xs, xb = extra
-        nx = int(xv.shape[1]) if xv.dim() == 2 else -1
-        if nx not in (4, 8) or xv.shape[0] != P:
-            raise RuntimeError("extra channels must have shape (num_points, 4) or (num_points, 8)")
+        x_per_view = int(xv.dim() == 3)
+        nx = int(xv.shape[-1]) if xv.dim() in (2, 3) else -1
+        if nx not in (4, 8) or xv.shape[-2] != P or (x_per_view and xv.shape[0] != V):
+            raise RuntimeError("extra channels must have shape (num_points, 4 or 8) or (num_views, num_points, 4 or 8)")
         if xb.numel() != nx or (xs is not None and tuple(xs.shape) != (V, nx)):
             raise RuntimeError("bg_extra must have nx entries and view_scale shape (V, nx)")
     if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned
@@ -420,7 +422,7 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
                 if nx:
                     return lib.gsr_forward_batch_channels(
                         C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(), binning.data_ptr(),
-                        binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, resume, nx, xv.data_ptr(),
+                        binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, resume, nx, x_per_view, xv.data_ptr(),
                         None if xs is None else xs.data_ptr(), xb.data_ptr(), out_extra.data_ptr(), stream)
                 return lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
                                              binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts,

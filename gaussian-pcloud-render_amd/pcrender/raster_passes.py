@@ -7,6 +7,10 @@ Mirrors, for inference use (the reference calls these under torch.no_grad(), sim
 `rasterize_views` is the literal call pattern: one GaussianRasterizer call per (batch item, view), stack,
 bilinear down-filter when super_sample_rate > 1, permute to (b, q, h, w, 3).
 
+`literal_passes` is the reference's pass sequence as it stands: one `rasterize_views` per pass, in PCML_Render.render's order (world
+xyz, SH colour, hit map, normals; :387-524) or Simple_Render.render's (:740-820), pinned call by call -- every argument of every
+rasterizer call and the post-processed results -- by tests/golden/py_rasterize_calls.npz, the trace of the reference's own code.
+
 `render_passes` produces the same four images per view but runs the geometry (preprocess, depth sort, pair
 emission, tile sort, ranges) ONCE per view -- all views in one submission (C ABI gsr_forward_batch) -- and re-renders the
 other colours on it with diff_gaussian_rasterization._native.recolor (C ABI gsr_forward_recolor), again all views per
@@ -59,49 +63,97 @@ def _finish(frames, batchsize, num_q, h, w, ss):
 
 def rasterize_views(means3D_list, opacity_list, scales_list, rotations_list, H_c2w, h, w, fov, bg, scale_factor,
                     shs_list=None, colors_list=None, sh_degree=1, super_sample_rate=2, normalize_camera_normal=False,
-                    batch_views=False):
+                    batch_views=False, simple=False):
     """The reference's _rasterize: lists are per batch item, H_c2w is [b, q, 4, 4] (Camera.H_c2w).  batch_views=True submits
     the q views of a batch item in ONE rasterizer call (diff_gaussian_rasterization.rasterize_views; same images, gradients
-    summed over the views like autograd does for the loop) whenever the colours do not depend on the view."""
+    summed over the views like autograd does for the loop) whenever the colours do not depend on the view.
+    simple=False: PCML_Render._rasterize (simple_raw_render.py:227-288), which scales the decoded scales by
+    sqrt(3) / scale_factor * 6; simple=True: Simple_Render._rasterize (:599-660), which takes the scales as they are (the factor
+    is commented out there, :617) and renders with opacity 1 whatever it is given (:616)."""
     batchsize, num_q = H_c2w.shape[0], H_c2w.shape[1]
     frames = []
     for i in range(batchsize):
         means3D = means3D_list[i]
         device = means3D.device
         means2D = torch.zeros_like(means3D, dtype=torch.float32, requires_grad=True, device=device) + 0
-        radius = float(np.sqrt(3) / scale_factor * 6)   # simple_raw_render.py:248
-        scales = scales_list[i] * radius
+        if simple:
+            scales, opacity_i = scales_list[i], torch.ones_like(opacity_list[i])
+        else:
+            radius = float(np.sqrt(3) / scale_factor * 6)   # simple_raw_render.py:248
+            scales, opacity_i = scales_list[i] * radius, opacity_list[i]
         colors_i = None if colors_list is None else colors_list[i]
         sts = settings_for_views(H_c2w[i], w, h, fov, device, sh_degree=sh_degree, bg=bg, super_sample_rate=super_sample_rate)
         if batch_views and not normalize_camera_normal:
-            imgs, _ = _rasterize_views_call(means3D, means2D, opacity_list[i], sts, shs=None if shs_list is None else shs_list[i],
+            imgs, _ = _rasterize_views_call(means3D, means2D, opacity_i, sts, shs=None if shs_list is None else shs_list[i],
                                             colors_precomp=colors_i, scales=scales, rotations=rotations_list[i])
             frames.extend(list(imgs))
             continue
         for j in range(num_q):
             st = sts[j]
-            if normalize_camera_normal:                 # simple_raw_render.py:264-268, incl. the sign-of-first-point quirk (Q11)
+            if normalize_camera_normal:
+                # simple_raw_render.py:264-268: every normal is turned towards the camera of the view being rendered, and the
+                # turned array is carried into the next view.  (camera_orig is [1,1,3] there, so the sign tensor is [1,N,1] and its
+                # `[0]` strips the BATCH axis: the signs are per point -- the call trace of the reference's own loop,
+                # tests/golden/py_rasterize_calls.npz, shows 24 different sign patterns; SURVEY.md's quirk Q11 misread it.)
                 cam_orig = H_c2w[i, j, :3, 3].to(device)
                 sgn = (torch.sum((means3D - cam_orig) * colors_i, -1, keepdim=True) > 0).float() * 2 - 1
-                colors_i = colors_i * (-1) * sgn[0]
+                colors_i = colors_i * (-1) * sgn
             img, _ = GaussianRasterizer(st)(
                 means3D=means3D, means2D=means2D, shs=None if shs_list is None else shs_list[i], colors_precomp=colors_i,
-                opacities=opacity_list[i], scales=scales, rotations=rotations_list[i], cov3D_precomp=None)
+                opacities=opacity_i, scales=scales, rotations=rotations_list[i], cov3D_precomp=None)
             frames.append(img)
     return _finish(frames, batchsize, num_q, h, w, super_sample_rate)
 
 
-def normal_view_signs(means3D, normals, cam_origins):
-    """The factors c_j with which the reference's per-view loop (simple_raw_render.py:264-268) ends up multiplying the normals
-    of view j: sgn_j = +1 iff (p0 - cam_j) . (c_(j-1) n0) > 0 for the FIRST point, c_j = -c_(j-1) * sgn_j, c_(-1) = 1.
-    One reduction over the q camera origins instead of q rounds of full-array kernels."""
-    dots = torch.sum((means3D[0:1] - cam_origins) * normals[0:1], -1).cpu()      # [q], the reference's expression for point 0
-    c, cs = 1.0, []
+def pcgc_rescale(xyz, offset=512, factor=256):
+    """voxel coordinates -> world units in float32 torch arithmetic (simple_raw_render.py:73-77)"""
+    return (xyz - offset) / factor
+
+
+def simple_primitives(points, colors, sigma=1., scale_factor=1., voxelized=True, offset=512):
+    """Simple_Render's per-Gaussian inputs from positions and colours in [0, 1] (simple_raw_render.py:688-726), torch float32 like
+    the reference: SH = [RGB2SH(colour) | 12 zero rows] (sh_deg 1 -> pseudo_sh_dim 12 -> M = 13), identity quaternions, isotropic
+    scales sigma (/ scale_factor for voxelised input), opacity 1, means = pcgc_rescale(points) if voxelised."""
+    dc = ((colors - 0.5) / 0.28209479177387814).unsqueeze(-2)                    # models/sh_utils.py:114-115
+    shs = torch.cat([dc, torch.zeros((colors.shape[0], 12, 3), device=colors.device)], dim=1)
+    quat = torch.tensor([1, 0, 0, 0], dtype=torch.float32, device=colors.device).expand(colors.shape[0], 4)
+    norm = scale_factor if voxelized else 1.
+    return dict(means3D=pcgc_rescale(points.float(), offset, scale_factor) if voxelized else points.float(), shs=shs, rotations=quat,
+                scales=torch.ones_like(colors[:, 0:3]) * sigma / norm, opacities=torch.ones_like(colors[:, 0:1]))
+
+
+def literal_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, background_color, scale_factor, normals=None,
+                   sh_degree=1, super_sample_rate=2, simple=False):
+    """The reference's passes, one full `rasterize_views` each: PCML_Render.render's xyz_w, rgb, hitmap, normal
+    (simple_raw_render.py:387-524) or, simple=True, Simple_Render.render's rgb, xyz_w, hitmap (:740-820; scales taken as they are,
+    opacity 1) for ONE cloud (the reference keeps batch item 0, :377-382) and the q views of H_c2w [q,4,4].  Returns the
+    reference's ret_dict: (1, q, h, w, 3) tensors."""
+    order = ("rgb", "xyz_w", "hitmap", "normal") if simple else ("xyz_w", "rgb", "hitmap", "normal")
+    bg = torch.zeros(3, device=means3D.device) + background_color                # :398
+    colours = {"xyz_w": means3D, "hitmap": torch.ones_like(means3D), "normal": normals}
+    out = {"rgb": None, "normal": None, "xyz_w": None, "hitmap": None}
+    for name in order:
+        if name == "normal" and normals is None:
+            continue
+        out[name] = rasterize_views(
+            [means3D], [opacities], [scales], [rotations], H_c2w.unsqueeze(0), h, w, fov, bg, scale_factor,
+            shs_list=[shs] if name == "rgb" else None, colors_list=None if name == "rgb" else [colours[name]],
+            sh_degree=sh_degree, super_sample_rate=super_sample_rate, normalize_camera_normal=(name == "normal"), simple=simple)
+    return out
+
+
+def normals_per_view(means3D, normals, cam_origins):
+    """What the reference's per-view loop renders as normals in view j (simple_raw_render.py:264-268), for all views: [q,N,3].
+    n_j = -n_(j-1) * sgn_j with sgn_j = +1 where (p - cam_j) . n_(j-1) > 0, else -1, per point, n_(-1) = the given normals: every
+    normal ends up turned towards camera j; a normal at exactly 90 degrees keeps the direction the previous view left it with,
+    which is why the views are walked in order like the reference does.  The same torch expressions as the loop, so the values are
+    the loop's bit for bit (multiplying by +-1 is exact)."""
+    cur, out = normals, []
     for j in range(cam_origins.shape[0]):
-        sgn = 1.0 if float(dots[j]) * c > 0 else -1.0
-        c = c * (-1.0) * sgn
-        cs.append(c)
-    return cs
+        sgn = (torch.sum((means3D - cam_origins[j]) * cur, -1, keepdim=True) > 0).float() * 2 - 1
+        cur = cur * (-1) * sgn
+        out.append(cur)
+    return torch.stack(out, 0)
 
 
 @torch.no_grad()
@@ -111,10 +163,10 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
     (1, q, h, w, 3) tensors: 'rgb', 'xyz_w', 'hitmap' and 'normal' (None without normals).
 
     All q views go through the pipeline in ONE submission, and the four passes in ONE render: world xyz, the hit map and the
-    normals are extra channels of the colour render (gsr_forward_batch_channels; the normals with a per-view sign: the reference
-    flips them view by view).  With a background whose three values differ the hit map's channels differ too, and the passes
-    are re-rendered one by one on the sorted lists instead (gsr_forward_recolor).  Inference only (no autograd graph), like
-    the reference's use."""
+    normals are extra channels of the colour render (gsr_forward_batch_channels; the normals as one value array per view: the
+    reference turns every normal towards the camera of the view it renders).  With a background whose three values differ the
+    hit map's channels differ too, and the passes are re-rendered one by one on the sorted lists instead (gsr_forward_recolor).
+    Inference only (no autograd graph), like the reference's use."""
     device = means3D.device
     num_q = H_c2w.shape[0]
     radius = float(np.sqrt(3) / scale_factor * 6)
@@ -129,29 +181,24 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
                         H_cpu[:, :3, 3]], dim=1).to(device)
     view, proj, cam = packed[:, :16].contiguous(), packed[:, 16:32].contiguous(), packed[:, 32:35].contiguous()
     bg_d = torch.zeros(3, device=device) if bg is None else bg.to(device)
-    cs = None
-    if normals is not None:
-        # simple_raw_render.py:264-268 flips the normals view by view with the sign found for the FIRST point (quirk Q11) and
-        # carries the flipped array into the next view: colours_j = c_j * normals with c_j = -c_(j-1) * sgn_j, sgn_j = +1 iff
-        # (p0 - cam_j) . (c_(j-1) n0) > 0.  Multiplying by +-1 is exact, so the scalars c_j follow from the q dot products of
-        # the first point alone.
-        cs = normal_view_signs(means3D, normals, packed[:, 35:38])
+    nv = None if normals is None else normals_per_view(means3D, normals, packed[:, 35:38])        # [q, P, 3]
     bg_cpu = bg if (bg is not None and bg.device.type == "cpu") else bg_d.cpu()
     if float(bg_cpu[0]) == float(bg_cpu[1]) == float(bg_cpu[2]):
         # ONE render for the four passes: world xyz, the hit map's single channel and the normals ride along as extra channels
         # of the colour render (gsr_forward_batch_channels) -- same alphas, same stopping decisions, the same sums term for term
         P = means3D.shape[0]
         one = torch.ones((P, 1), dtype=torch.float32, device=device)
-        nrm = normals if normals is not None else torch.zeros_like(means3D)
-        extra = torch.cat([means3D, one, nrm, torch.zeros_like(one)], dim=1).contiguous()                   # [P, 8]
-        scale = torch.ones((num_q, 8), dtype=torch.float32)
-        if cs is not None:
-            scale[:, 4:7] = torch.tensor(cs, dtype=torch.float32).reshape(num_q, 1)
+        if nv is None:
+            extra = torch.cat([means3D, one], dim=1).contiguous()                                           # [P, 4], shared by the views
+        else:
+            extra = torch.cat([means3D.unsqueeze(0).expand(num_q, P, 3), one.unsqueeze(0).expand(num_q, P, 1), nv,
+                               torch.zeros((num_q, P, 1), dtype=torch.float32, device=device)], dim=2).contiguous()   # [q, P, 8]
+        nx = extra.shape[-1]
         counts, rgb, radii, geom, binning, img, ex = _native.rasterize_gaussians_batch(
             bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
-            False, False, need_backward=False, extra=(extra, scale.to(device), bg_d[0:1].expand(8)))
+            False, False, need_backward=False, extra=(extra, None, bg_d[0:1].expand(nx)))
         out = {"rgb": rgb, "xyz_w": ex[:, 0:3], "hitmap": ex[:, 3:4].expand(num_q, 3, H, W),
-               "normal": None if normals is None else ex[:, 4:7]}
+               "normal": None if nv is None else ex[:, 4:7]}
     else:
         counts, rgb, radii, geom, binning, img = _native.rasterize_gaussians_batch(
             bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
@@ -160,8 +207,6 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
         def again(colors):
             return _native.recolor(bg_d, means3D, colors, e, 0, cam, H, W, counts, geom, binning, img).reshape(num_q, 3, H, W)
 
-        out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)), "normal": None}
-        if normals is not None:
-            per_view = normals.unsqueeze(0) * torch.tensor(cs, device=device, dtype=normals.dtype).reshape(num_q, 1, 1)
-            out["normal"] = again(per_view.contiguous())
+        out = {"rgb": rgb, "xyz_w": again(means3D), "hitmap": again(torch.ones_like(means3D)),
+               "normal": None if nv is None else again(nv.contiguous())}
     return {k: (None if v is None else _finish(v, 1, num_q, h, w, super_sample_rate)) for k, v in out.items()}

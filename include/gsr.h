@@ -123,16 +123,17 @@ int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes,
                       int resume, gsr_stream_t stream);
 
 /* gsr_forward_batch that also composites `nx` (4 or 8; pad with zero channels) extra per-Gaussian channels with the SAME alphas,
- * transmittances and stopping decisions as the colour: out_extra[v][k] = sum_i extra[i][k] * view_scale[v][k] * alpha_i * T_i +
+ * transmittances and stopping decisions as the colour: out_extra[v][k] = sum_i extra[v][i][k] * view_scale[v][k] * alpha_i * T_i +
  * T_final * bg_extra[k], term for term what a separate call with colors_precomp = those channels would produce -- the
  * reference's callers render world xyz, a hit map and normals that way, one full rasterizer call each
- * (simple_raw_render.py:410-524), recomputing identical alphas four times.  extra [P][nx] is shared by the views;
- * extra_view_scale [V][nx] (or NULL) multiplies it per view (the reference flips normals view by view).
+ * (simple_raw_render.py:410-524), recomputing identical alphas four times.  extra_per_view = 0: extra [P][nx] is shared by the
+ * views; 1: extra [V][P][nx], one array per view (the reference turns every normal towards the camera of the view it renders,
+ * simple_raw_render.py:264-268).  extra_view_scale [V][nx] (or NULL) multiplies the values per view and channel.
  * out_extra is [V][nx][H][W].  P == 0: nothing is written (like out_color).  Same GSR_RETRY / resume contract. */
 int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
                                void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume,
-                               int nx, const float* extra, const float* extra_view_scale, const float* bg_extra, float* out_extra,
-                               gsr_stream_t stream);
+                               int nx, int extra_per_view, const float* extra, const float* extra_view_scale, const float* bg_extra,
+                               float* out_extra, gsr_stream_t stream);
 
 /* The reference's synchronous shape for one view.  Stage 1: preprocess, depth ordering, pair counting; returns
  * num_rendered through *num_rendered_out after a device->host read-back on `stream` (cf. rasterizer_impl.cu:281).

@@ -13,7 +13,17 @@
                    RegularGridInterpolator) on a seeded 7x5 RGB texture: uv inside, on the texel centres, on the borders, and
                    outside [0,1) (wrap).  Pins pcrender.mesh_sample.uv_lookup.
 
-Usage: python tests/golden/make_golden_py.py [sh|camera|uvmap ...]
+  py_rasterize_calls.npz : the CALL TRACE of the reference's caller glue.  PCML_Render.render (simple_raw_render.py:290-524: the
+                   four passes world-xyz / SH colour / hit map / normals, each through PCML_Render._rasterize, :227-288) and
+                   Simple_Render.render (:662-854: three passes) are driven as they stand on a seeded toy input (24 points, four
+                   circle views of 8x6 px, super-sample 2) with a RECORDING stand-in for GaussianRasterizer that returns seeded fake
+                   images: what is stored is every argument of every rasterizer call (scales after the sqrt(3)/scale_factor*6
+                   factor, colors_precomp after the per-view normal-sign flip of :264-268, the settings built per call) and the
+                   dictionaries render() returns from the fake images (stack, bilinear down-filter, permute).  The network, its
+                   checkpoint and MinkowskiEngine are not on this path's arithmetic: the model is a stub that returns the seeded
+                   primitives, PCML_Render.__init__ (checkpoint loading) is bypassed.  Pins pcrender.raster_passes.
+
+Usage: python tests/golden/make_golden_py.py [sh|camera|uvmap|calls ...]
 """
 import os
 import sys
@@ -48,7 +58,10 @@ def sh_vectors():
     print("py_sh_eval.npz written")
 
 
-def camera_vectors():
+def _import_reference_caller():
+    """simple_raw_render with the third-party modules it never calls on this path replaced by mocks"""
+    if "simple_raw_render" in sys.modules:
+        return sys.modules["simple_raw_render"]
     for name in ["MinkowskiEngine", "open3d", "imageio", "cv2", "torch_scatter", "xatlas", "skimage", "skimage.metrics",
                  "pyexr", "matplotlib", "matplotlib.pyplot", "matplotlib.font_manager", "mpl_toolkits",
                  "mpl_toolkits.axes_grid1", "lpips", "pytorch_msssim", "tqdm", "diff_gaussian_rasterization"]:
@@ -78,6 +91,11 @@ def camera_vectors():
         import simple_raw_render as srr
     finally:
         os.chdir(cwd)
+    return srr
+
+
+def camera_vectors():
+    srr = _import_reference_caller()
     out = {}
     fix = torch.load(os.path.join(REF, "validate", "temp_state_dict.pt"))
     out["fixture_H_c2w"] = fix["H_c2w"].numpy()
@@ -125,11 +143,92 @@ def uvmap_vectors():
     print("py_uvmap.npz written", out.shape)
 
 
+def call_trace_vectors():
+    srr = _import_reference_caller()
+    rng = np.random.default_rng(4242)
+    n, h, w, ss, fov, sf, offset = 24, 6, 8, 2, 45.0, 256.0, 512
+    calls = []
+
+    class RecordingRasterizer:
+        """stands where diff_gaussian_rasterization.GaussianRasterizer stands in the reference's module"""
+        def __init__(self, raster_settings):
+            self.st = raster_settings
+
+        def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+            k = len(calls)
+            st = self.st
+            rec = dict(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                       rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=st.viewmatrix.contiguous().reshape(4, 4),
+                       projmatrix=st.projmatrix.contiguous().reshape(4, 4), campos=st.campos.reshape(3), bg=st.bg,
+                       scalars=torch.tensor([st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.scale_modifier, st.sh_degree,
+                                             float(st.prefiltered), float(st.debug)], dtype=torch.float64))
+            calls.append({a: (None if v is None else v.detach().clone().numpy()) for a, v in rec.items()})
+            img = torch.from_numpy(np.random.default_rng(9000 + k).random((3, st.image_height, st.image_width), dtype=np.float32))
+            return img, torch.zeros(means3D.shape[0], dtype=torch.int32)
+
+    srr.GaussianRasterizer = RecordingRasterizer
+    # the caller writes device="cuda" literally (simple_raw_render.py:241) and synchronises around its timers: run it on the CPU
+    zeros_like = torch.zeros_like
+    torch.zeros_like = lambda *a, **k: zeros_like(*a, **{**k, "device": "cpu"} if k.get("device") == "cuda" else k)
+    torch.cuda.synchronize = lambda *a, **k: None
+    cam = srr.generate_cam({'fov': fov, 'width_px': w, 'height_px': h, 'mode': 'circle', 'n_imgs': 4, 'd': 0, 'r': 3,
+                            'center_angles': [90, 0], 'alt_yaxis': False}, save_temp_state_dict=False)
+    out = {"H_c2w": cam.H_c2w.numpy(), "args": np.array([n, h, w, ss, fov, sf, offset], dtype=np.float64)}
+
+    # ---- PCML_Render.render: the network is a stub handing back seeded primitives (voxel coordinates, like the decoder's output)
+    vox = torch.from_numpy(rng.integers(400, 624, (n, 3)).astype(np.float32))
+    prim = dict(
+        decoded_primitives=[vox], decoded_sh=[torch.from_numpy(rng.standard_normal((n, 13, 3)).astype(np.float32))],
+        decoded_r=[torch.from_numpy((np.array([1, 0, 0, 0]) + 0.05 * rng.standard_normal((n, 4))).astype(np.float32))],
+        decoded_s=[torch.from_numpy(np.clip(1 + 0.15 * rng.standard_normal((n, 3)), 0, None).astype(np.float32))],
+        decoded_o=[torch.from_numpy(rng.uniform(0.2, 1.0, (n, 1)).astype(np.float32))],
+        decoded_n=[torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32))])
+    for k, v in prim.items():
+        out["pcml_" + k] = v[0].numpy()
+    model_out = (prim["decoded_primitives"], prim["decoded_sh"], prim["decoded_r"], prim["decoded_s"], prim["decoded_o"], 0.0,
+                 None, None, None, 0.0, 0.0, prim["decoded_n"])
+    r = object.__new__(srr.PCML_Render)            # __init__ loads a checkpoint: not on this path
+    r.device = torch.device("cpu")
+    r.model = lambda sparse: model_out
+    r.info = {"clr_encoder_channels": "3 64", "sh_deg": 1, "scale_factor": sf}
+    r.voxelized, r.scale_factor, r.offset = True, sf, offset
+    srr.ME.utils.sparse_collate = lambda pts, feats: (pts, feats)
+
+    class _Pcd:
+        xyz_w = [vox.clone()]
+        rgb = [torch.from_numpy(rng.uniform(0, 1, (n, 3)).astype(np.float32))]
+
+    ret = r.render(_Pcd(), 1, cam, fov, enable_opacity=True, super_sample_rate=ss, background_color=1.0)
+    n_pcml = len(calls)
+    for k in ("xyz_w", "rgb", "hitmap", "normal"):
+        out["pcml_ret_" + k] = ret[k].numpy()
+
+    # ---- Simple_Render.render (no network): isotropic splats from positions + colours
+    sr = srr.Simple_Render(voxelized=True, scale_factor=sf, offset=offset)
+    sr.device = torch.device("cpu")
+    sr.default_quaternion = sr.default_quaternion.cpu()
+    out["simple_xyz"], out["simple_rgb"] = _Pcd.xyz_w[0].numpy(), _Pcd.rgb[0].numpy()
+    ret2 = sr.render(_Pcd(), 1, cam, fov, enable_opacity=True, super_sample_rate=ss, background_color=0.0, sigma=1.5)
+    for k in ("rgb", "xyz_w", "hitmap"):
+        out["simple_ret_" + k] = ret2[k].numpy()
+    assert ret2["normal"] is None
+    out["n_calls"] = np.array([n_pcml, len(calls) - n_pcml])
+    for k, c in enumerate(calls):
+        for a, v in c.items():
+            if v is not None:
+                out["call%02d_%s" % (k, a)] = v
+    torch.zeros_like = zeros_like
+    np.savez_compressed(os.path.join(OUT, "py_rasterize_calls.npz"), **out)
+    print("py_rasterize_calls.npz written: %d + %d calls" % (n_pcml, len(calls) - n_pcml))
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["sh", "camera", "uvmap"]
+    todo = sys.argv[1:] or ["sh", "camera", "uvmap", "calls"]
     if "sh" in todo:
         sh_vectors()
     if "camera" in todo:
         camera_vectors()
     if "uvmap" in todo:
         uvmap_vectors()
+    if "calls" in todo:
+        call_trace_vectors()

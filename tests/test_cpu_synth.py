@@ -44,8 +44,10 @@ def test_batched_view_settings_are_bit_identical_to_per_view():
             assert torch.equal(a[k], b[k][j]), (k, j)
 
 
-def test_normal_view_signs_match_the_reference_loop():
-    """raster_passes.normal_view_signs against the literal per-view loop of simple_raw_render.py:264-268 (CPU tensors)."""
+def test_normals_per_view_match_the_reference_loop():
+    """raster_passes.normals_per_view against the per-view loop of simple_raw_render.py:264-268 written out with the reference's
+    tensor shapes (camera origin [1,1,3], hence a [1,N,1] sign tensor whose `[0]` strips the batch axis: per-POINT signs; the
+    trace of the reference's own loop is in tests/test_cpu_call_trace.py)."""
     import torch
     from pcrender import camera, raster_passes as rp
     g = torch.Generator().manual_seed(5)
@@ -56,9 +58,12 @@ def test_normal_view_signs_match_the_reference_loop():
         if trial == 0:
             normals[0] = 0.0                     # the dot product of the first point is exactly 0 in every view
         cams = Hs[:, :3, 3]
-        cs = rp.normal_view_signs(means, normals, cams)
+        nv = rp.normals_per_view(means, normals, cams)
         colors = normals
         for j in range(12):
-            sgn = (torch.sum((means - cams[j]) * colors, -1, keepdim=True) > 0).float() * 2 - 1
+            camera_orig = Hs[None, j:j + 1, :3, 3]                               # Camera.get_camera_origin_w() of a [1,1,4,4] chunk
+            sgn = (torch.sum((means - camera_orig) * colors, -1, keepdim=True) > 0).float() * 2 - 1
             colors = colors * (-1) * sgn[0]
-            assert torch.equal(colors, normals * cs[j]), (trial, j)
+            assert torch.equal(colors, nv[j]), (trial, j)
+        # every normal faces its view's camera afterwards (or is perpendicular to the viewing ray)
+        assert bool((torch.sum((means[None] - cams[:, None]) * nv, -1) <= 0).all())

@@ -146,7 +146,7 @@ def test_config0_thuman256_native_raster_four_passes_vs_oracle(oracle, gpu_devic
         assert a["image_height"] == 1024 and a["image_width"] == 1024
         cam_orig = Hs[j, :3, 3]
         sgn = (torch.sum((means_t - cam_orig) * colors_n, -1, keepdim=True) > 0).float() * 2 - 1
-        colors_n = colors_n * (-1) * sgn[0]                       # carried across views like the reference's loop (quirk Q11)
+        colors_n = colors_n * (-1) * sgn                          # per point, carried across views (simple_raw_render.py:264-268)
         passes = dict(rgb=dict(shs=g["shs"], sh_degree=1), xyz_w=dict(colors_precomp=g["means3D"]),
                       hitmap=dict(colors_precomp=np.ones_like(g["means3D"])), normal=dict(colors_precomp=colors_n.numpy()))
         for name, kw in passes.items():

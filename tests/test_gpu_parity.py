@@ -144,6 +144,32 @@ def test_mark_visible(oracle, gpu_device):
                          torch.from_numpy(s.projmatrix.reshape(4, 4)).to(gpu_device)).cpu().numpy()
     np.testing.assert_array_equal(got, want)
     assert 0 < want.sum() < want.size
+    # and against the reference's own checkFrustum / markVisible (CR/rasterizer_impl.cu:54-66,141-153) built for this GPU
+    np.testing.assert_array_equal(got, _ref("strict").mark_visible(s.means3D, s.viewmatrix, s.projmatrix))
+
+
+@pytest.mark.parametrize("name", ["capsule_circle", "random_aniso", "all_culled", "one_gaussian"])
+def test_mark_visible_vs_reference_build(name, gpu_device):
+    """markVisible against the reference build on more clouds, including points straddling the near plane (z_view within a few
+    ulps of 0.2, where `p_view.z <= 0.2f` decides)"""
+    import torch
+    from diff_gaussian_rasterization import _native as N
+    ref = _ref("strict")
+    s = build_scene(name)
+    means = s.means3D.copy()
+    if s.P >= 64:
+        # push a block of points onto the near plane z_view = 0.2 +- a few ulps: view . (p, 1) row 2 (column-major flattened matrix)
+        v = s.viewmatrix.reshape(16).astype(np.float64)
+        dirz = np.array([v[2], v[6], v[10]])
+        for k in range(48):
+            p = means[k].astype(np.float64)
+            z = dirz @ p + v[14]
+            p = p + dirz / (dirz @ dirz) * (0.2 - z)
+            means[k] = np.nextafter(p.astype(np.float32), np.float32(np.inf if k % 2 else -np.inf) , dtype=np.float32) if k % 3 else p.astype(np.float32)
+    want = ref.mark_visible(means, s.viewmatrix, s.projmatrix)
+    got = N.mark_visible(torch.from_numpy(means).to(gpu_device), torch.from_numpy(s.viewmatrix.reshape(4, 4)).to(gpu_device),
+                         torch.from_numpy(s.projmatrix.reshape(4, 4)).to(gpu_device)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
 
 
 def test_fma_contraction_moves_few_decisions(gpu_device):
