@@ -21,8 +21,12 @@ Beside the headline the line carries (rank 0, measured right after the timed reg
                   VALU issue rate, and -- only if profiles/pmc_traffic.json was taken on exactly this workload and call shape -- the
                   counter traffic and the profile's own duration of that kernel (`profile_avg_ms`, `frac_profile`,
                   `live_vs_profile`); `traffic` is null otherwise;
-  drop_in_api  -- the same frames through the reference's call pattern (one GaussianRasterizer call per view,
-                  /root/reference/simple_raw_render.py:259-278): frames/s on one and on four streams and its own per-stage times;
+  drop_in      -- the CO-HEADLINE: the same frames through the reference's API exactly as its caller uses it
+                  (/root/reference/simple_raw_render.py:259-278): per view, fresh settings tensors built inside the timed loop, one
+                  GaussianRasterizer(settings)(...) call, loss.backward(); one thread, one stream, in order; plus the same figure
+                  from --drop-in-processes (default 5) FRESH processes (min / median / max);
+  drop_in_api  -- variants of it (prebuilt settings; the opt-in overlap of consecutive calls; four caller threads) and the
+                  per-stage times of the per-view call;
   forward_only -- inference frames/s of both call shapes;
   rgb_time_equiv -- the reference's own timing hook (`rgb time`, simple_raw_render.py:433-456): 12 views x 1024^2 (512^2 camera,
                   super-sample 2), the SH colour pass, INCLUDING per-view settings glue and the bilinear down-filter;
@@ -54,6 +58,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+import hashlib  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches (same guide)
 VALU_PEAK_GWIPS = 1228.9     # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
@@ -63,6 +69,18 @@ STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_ren
 
 
 GC_RECOVER_S = 0.15   # untimed load between the garbage collection and the first timed block (seconds)
+
+
+def kernels_sha():
+    """identity of the kernel sources this process runs (csrc/*.hip, *.hpp + include/gsr.h): counter profiles taken on other
+    kernels are not quoted (roofline.traffic is null then)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaussian-pcloud-render_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/gsr.h"]:
+        if f.endswith((".hip", ".hpp", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes, views_per_call=1):
@@ -157,6 +175,10 @@ def main():
                          "rasterize_views (C ABI gsr_forward_batch / gsr_backward_batch), V views of the cloud in one submission; "
                          "0 = the config's default: 12 (one turn of the circle) for configs 1 / 2, the rank's own views for 3 / 4")
     ap.add_argument("--no-per-view", action="store_true", help="skip the drop-in-API / forward-only / rgb-time side measurements")
+    ap.add_argument("--drop-in-processes", type=int, default=5,
+                    help="fresh processes that each measure the drop-in figure on their own (min / median / max in the line: the "
+                         "figure must not depend on how a process happened to set up its streams); 0 = skip")
+    ap.add_argument("--drop-in-probe", action="store_true", help=argparse.SUPPRESS)   # what those processes run
     ap.add_argument("--no-stage-events", action="store_true",
                     help="no per-stage hipEvents anywhere (for timeline traces: an event pair costs ~10 us of bubble per stage)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
@@ -200,6 +222,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev_index = local_rank if args.device_index < 0 else args.device_index
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d (local rank %d) wants GPU %d but only %d are visible: one device per rank"
+                         % (rank, local_rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     host_collectives = args.dist_backend == "gloo"
@@ -231,6 +256,11 @@ def main():
         viewmatrix=v["viewmatrix"].to(dev), projmatrix=v["projmatrix"].to(dev), sh_degree=D, campos=v["campos"].to(dev),
         prefiltered=False, debug=False) for v in views]
     rasterizers = [GaussianRasterizer(s) for s in settings]
+    from pcrender import raster_passes as _rp
+    H_c2w_views = camera.circle_path(n_views, 0, 3, [90, 0])     # the poses `views` was built from (camera.circle_views)
+    if world > 1:
+        # one process per GPU on a shared host: keep every rank's host-side thread pools (torch CPU ops, OpenMP) to its share
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
 
     grad = not args.forward_only
 
@@ -288,7 +318,28 @@ def main():
             img, _ = rasterizers[v](**L)
         return img
 
+    literal_mode = [False]
+
+    def render_literal(i, tslot=0, with_grad=True):
+        """The reference caller's loop body, literally (simple_raw_render.py:260-278): the settings of the view are BUILT for this
+        call (get_rasterize_param_from_camera's arithmetic on the host, fresh device tensors), a GaussianRasterizer is made from
+        them, called, and the loss is backpropagated."""
+        v = view_of(i, rank, world, n_views, shard)
+        L = leafsets[tslot]
+        st = _rp.settings_for_view(H_c2w_views[v], W, H, 45.0, dev, sh_degree=D, bg=bg, super_sample_rate=1)
+        if with_grad:
+            img, _ = GaussianRasterizer(st)(**L)
+            (img * G).sum().backward()
+            for t in L.values():
+                t.grad = None
+            return img.detach()
+        with torch.no_grad():
+            img, _ = GaussianRasterizer(st)(**L)
+        return img
+
     def render_many(i, n, tslot=0, with_grad=True):
+        if literal_mode[0] and n == 1:
+            return bracket(lambda: render_literal(i, tslot, with_grad)[None])
         return bracket(lambda: render_many_(i, n, tslot, with_grad))
 
     def render_many_(i, n, tslot=0, with_grad=True):
@@ -376,6 +427,30 @@ def main():
             ms.setdefault(name, []).append(t)
         _native.set_profiling(False)
         return {k: float(np.mean(v)) for k, v in ms.items()}, d1
+
+    def drop_in_literal(blocks=3, frames=48):
+        """frames/s of the literal per-view loop: one thread, one stream, in order; median of `blocks` blocks after an untimed one"""
+        was = _native._OVERLAP_ON
+        _native.set_overlap(False)
+        literal_mode[0] = True
+        try:
+            run_steps(0, frames, streams=1, vpc=1, gather_on=False)
+            ts = [timed(frames, streams=1, vpc=1) for _ in range(blocks)]
+        finally:
+            literal_mode[0] = False
+            _native.set_overlap(was)
+        return frames / float(np.median(ts)), [round(frames / t, 1) for t in ts]
+
+    if args.drop_in_probe:
+        # a fresh process measuring only the drop-in figure (spawned by the main run, --drop-in-processes)
+        warm = 0
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.warmup_seconds:
+            run_steps(0, 24, streams=1, vpc=1, gather_on=False)
+            torch.cuda.synchronize()
+        fps, blocks = drop_in_literal()
+        print(json.dumps({"drop_in_frames_per_s": round(fps, 1), "blocks": blocks}))
+        return
 
     # untimed: the W warm-up steps asked for, plus priming of every stream's allocator pool / code objects
     # (3 frames per stream and 3 on the caller's stream) so that a small W does not put first-touch costs in the timing,
@@ -505,11 +580,16 @@ def main():
         drop_in = {"call": "GaussianRasterizer(settings_v)(means3D, means2D, opacities, shs=, scales=, rotations=) per view + "
                            "loss.backward() per view" if grad else "GaussianRasterizer(...) per view under no_grad",
                    "frames_per_s": {}}
-        # one_stream: ONE caller thread on one stream, prebuilt GaussianRasterizer objects (the settings tensors are the same objects
-        # every turn, so the library may start a view's front end beside the previous view's backward: _native._OnSideStream);
-        # one_stream_in_order: the same with that overlap switched off (what a caller gets who rebuilds the per-view matrices
-        # on the device before every call, like simple_raw_render.py:259-278 does); four_streams: four caller threads
-        for name, st, ovl in (("one_stream", 1, True), ("one_stream_in_order", 1, False), ("four_streams", 4, True)):
+        # literal: the reference caller's loop body as it stands -- settings built per call inside the timed loop (drop_in_literal);
+        # one_stream_in_order: prebuilt GaussianRasterizer objects, the library's default (plain stream order);
+        # one_stream_overlap_opt_in: the same with GSR_OVERLAP=1 (a view's front end starts beside the previous view's backward while
+        # every input tensor is provably unchanged; what it is worth depends on the hardware queues the runtime hands out, which is
+        # why it is off by default); four_streams: four caller threads, each with its own stream and leaf tensors
+        fps_lit, lit_blocks = drop_in_literal()
+        drop_in["frames_per_s"]["literal"] = round(fps_lit, 1)
+        drop_in["literal_blocks"] = lit_blocks
+        ovl_default = _native._OVERLAP_ON
+        for name, st, ovl in (("one_stream_in_order", 1, False), ("one_stream_overlap_opt_in", 1, True), ("four_streams", 4, False)):
             if st > len(leafsets):
                 continue
             _native.set_overlap(ovl)
@@ -518,9 +598,9 @@ def main():
             # three blocks of 48 (a single cold block of 48 frames reported 410-700 frames/s for what runs at 1 400)
             run_steps(warm, 48, streams=st, vpc=1, gather_on=False)
             drop_in["frames_per_s"][name] = round(48 / float(np.median([timed(48, streams=st, vpc=1) for _ in range(3)])), 1)
-            if name == "one_stream":
+            if name == "one_stream_overlap_opt_in":
                 drop_in["overlapped_calls"] = "%d of %d" % (_native.OVERLAP_STATS["overlapped"], _native.OVERLAP_STATS["calls"])
-        _native.set_overlap(True)
+        _native.set_overlap(ovl_default)
         pv_ms, _ = stage_pass(24, vpc=1)
         drop_in["kernels_ms_per_frame"] = {k: round(v, 4) for k, v in pv_ms.items()}
         drop_in["kernel_sum_ms_per_frame"] = round(sum(pv_ms.values()), 4)
@@ -559,6 +639,27 @@ def main():
                     rgb_time.setdefault("iterations_ms", {})[name] = [round(x, 2) for x in its]
         except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
             rgb_time = {"error": repr(ex)}
+    if drop_in is not None and args.drop_in_processes > 0 and world == 1:
+        # the drop-in figure from FRESH processes (each: import, build the cloud, one second of warm-up, three blocks of 48 frames):
+        # it must not depend on what this process did before, nor on how a process's streams happened to be set up
+        import subprocess
+        torch.cuda.synchronize()
+        cmdp = [sys.executable, os.path.abspath(__file__), "--drop-in-probe", "--config", str(args.config), "--workload", args.workload,
+                "--width", str(W), "--height", str(H), "--profile", args.profile, "--no-cpu-baseline"] + \
+               (["--points", str(args.points)] if args.points else []) + (["--forward-only"] if args.forward_only else [])
+        vals, errs = [], []
+        for _ in range(args.drop_in_processes):
+            try:
+                r = subprocess.run(cmdp, capture_output=True, text=True, timeout=300)
+                ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                vals.append(json.loads(ls[-1])["drop_in_frames_per_s"]) if ls else errs.append((r.stdout + r.stderr)[-200:])
+            except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
+                errs.append(repr(ex))
+        drop_in["fresh_processes"] = {"n": len(vals), "frames_per_s": vals,
+                                      "min": min(vals) if vals else None, "median": float(np.median(vals)) if vals else None,
+                                      "max": max(vals) if vals else None,
+                                      "spread": round((max(vals) - min(vals)) / float(np.median(vals)), 4) if vals else None,
+                                      "errors": errs or None}
     per_rank_blocks = None
     if use_dist:
         cdev = "cpu" if host_collectives else dev
@@ -568,6 +669,11 @@ def main():
         per_rank_blocks = [[float(x) for x in e.tolist()] for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         block_dt = [float(x) for x in t.tolist()]
+        # where every rank ran: (rank, local rank, device index, host threads), two int32 per field through the same backend
+        mine = torch.tensor([rank, local_rank, dev_index, torch.get_num_threads()], device=cdev, dtype=torch.int32)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        devs = [dict(zip(("rank", "local_rank", "device", "host_threads"), (int(x) for x in r.tolist()))) for r in allr]
     dt = float(np.median(block_dt))
 
     if rank == 0:
@@ -614,6 +720,10 @@ def main():
             if pmc.get("key") != key:
                 pmc_why = "profiles/pmc_traffic.json was taken on %s, this run is %s" % (json.dumps(pmc.get("key")), json.dumps(key))
                 pmc = None
+            elif pmc.get("kernels_sha") != kernels_sha():
+                pmc_why = ("profiles/pmc_traffic.json was taken on other kernel sources (kernels_sha %s, lease %s; this tree is %s): "
+                           "its counters are not quoted for this run" % (pmc.get("kernels_sha"), pmc.get("lease"), kernels_sha()))
+                pmc = None
         except (OSError, ValueError) as ex:
             pmc_why = "profiles/pmc_traffic.json: %r" % (ex,)
         if dom is not None:
@@ -623,8 +733,13 @@ def main():
             dom_clk = float(np.median(sclk_timed)) if (dom in inreg_ms and sclk_timed) else (float(np.median(sclk_stage)) if sclk_stage else None)
             achieved = bytes_per[dom] * VPC / (dom_ms * 1e-3) / 1e9     # a launch covers VPC views
             kname = STAGE_KERNEL.get(dom, dom)
+            # `bound` names the roof `achieved` / `peak` / `frac` are quoted against (the contract: algorithmic HBM bytes over the
+            # kernel's duration against the 8 TB/s peak); `binding_roof` names what actually limits the kernel
+            render_dom = dom in ("render_backward", "render_forward")
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "binding_roof": "valu (fp32 vector + matrix issue on the SIMDs; see `valu`)" if render_dom else "hbm",
+                        "binding_frac": None,
                         "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBS, 5),
                         "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(dom_ms, 4),
                         "avg_ms_measured": "hipEvents on the launch stream around every launch of this kernel inside the timed region "
@@ -635,10 +750,12 @@ def main():
                                 "the fraction of the HBM roofline is structurally small; see `valu`"}
             if pmc is not None:
                 roofline["traffic"] = pmc.get("bytes_per_launch", {}).get(kname)
-                roofline["traffic_source"] = ("(FETCH_SIZE x %s + WRITE_SIZE) per launch, rocprofv3 PMC passes of this command in the "
-                                              "same lease as the kernel trace (profiles/pmc_traffic.json; the FETCH factor is the one "
-                                              "profiles/r03_fetch_calibration.txt measures for this kernel's access pattern)"
-                                              % pmc.get("fetch_factor", {}).get(kname, pmc.get("fetch_factor", {}).get("default", 2)))
+                roofline["traffic_source"] = ("builder lease %s (kernels_sha %s = this tree's): (FETCH_SIZE x %s + WRITE_SIZE) per launch, "
+                                              "rocprofv3 PMC passes of this command in the same lease as the kernel trace "
+                                              "(profiles/pmc_traffic.json; the FETCH factor is the one the lease's fetch calibration "
+                                              "measures for this kernel's access pattern)"
+                                              % (pmc.get("lease"), pmc.get("kernels_sha"),
+                                                 pmc.get("fetch_factor", {}).get(kname, pmc.get("fetch_factor", {}).get("default", 2))))
                 pa = pmc.get("avg_us", {}).get(kname)
                 if pa:
                     roofline["profile_avg_ms"] = round(pa / 1e3, 4)
@@ -659,7 +776,12 @@ def main():
                     rate = valu / (dom_ms * 1e-3)
                     roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
                                         "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
-                                        "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json; duration measured live"}
+                                        "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json; duration measured live",
+                                        "note": "instructions per second against one plain wave64 instruction per SIMD per 2 cycles; "
+                                                "packed fp32 (4 cycles), transcendentals (8) and the backward's fp32 MFMAs (32) hold "
+                                                "their SIMD longer than that, so the SIMDs are busier than this fraction says"}
+                    if render_dom:
+                        roofline["binding_frac"] = roofline["valu"]["frac"]
             else:
                 roofline["traffic_source"] = "null: " + pmc_why
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
@@ -711,6 +833,12 @@ def main():
                                    "sample": "1 frame of the same view, %s, single thread (no warm-up: %.1f s of CPU work)" % (what, c1)}
                 cpu["speedup_over_one_core"] = round(c1 / cdt, 2)
 
+        ref_ctx = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "reference_build.json")) as f:
+                ref_ctx = json.load(f)
+        except (OSError, ValueError):
+            pass
         shape = ("%d views per rasterize_views call (C ABI gsr_forward_batch%s), %d call%s in flight per rank" % (
             VPC, " / gsr_backward_batch" if grad else "", args.streams, "s" if args.streams != 1 else "")) if VPC > 1 else (
             "one GaussianRasterizer call per view (the reference's call pattern), %d in flight per rank" % args.streams)
@@ -728,9 +856,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "python_gc": "collected before, disabled inside the timed region (like timeit)",
             "overlap_of_consecutive_calls": {"on": bool(_native._OVERLAP_ON), "calls_overlapped_in_timed_region": overlap_timed,
-                                             "note": "the library starts a call's front end beside the previous call's backward when every "
-                                                     "input tensor is provably unchanged (_native._OnSideStream; GSR_OVERLAP=0 switches it off); "
-                                                     "the per-stage pass below runs in stream order"},
+                                             "note": "opt-in (GSR_OVERLAP=1): the library then starts a call's front end beside the previous "
+                                                     "call's backward when every input tensor is provably unchanged (_native._OnSideStream); "
+                                                     "off by default: every kernel runs in the caller's stream order"},
             # GPU time of the TIMED steps themselves (rank 0): per block, the union of the submissions' [start, end] hipEvent
             # intervals on the streams they ran on (loss kernels included), and the block's wall time over it
             "gpu_ms_per_step_timed": round(float(np.median(gpu_busy_ms)) / args.steps, 4) if gpu_busy_ms else None,
@@ -762,6 +890,20 @@ def main():
                 "consumed_entries_fwd_avg": int(stats["C_fwd"]), "consumed_entries_bwd_avg": int(stats["C_bwd"])},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "kernels_sha": kernels_sha(),
+            # the reference's API as its caller uses it: per view, settings built inside the loop, one call, one backward; one thread,
+            # one stream, in order (drop_in_api has the variants)
+            "drop_in": None if drop_in is None else {
+                "frames_per_s": drop_in["frames_per_s"].get("literal"), "unit": "frames/s",
+                "fraction_of_value": round(drop_in["frames_per_s"].get("literal", 0.0) / (world * args.steps / dt), 4),
+                "what": "the reference caller's loop body as it stands (simple_raw_render.py:260-278): per view the settings are built "
+                        "for the call (fresh tensors), GaussianRasterizer(settings)(means3D, means2D, opacities, shs=, scales=, "
+                        "rotations=), loss.backward(); ONE thread, ONE stream, plain stream order (the library's default)",
+                "fresh_processes": drop_in.get("fresh_processes")},
+            "reference_build_context": ref_ctx,
+            "multi_gpu_status": "measured on %d GPU(s)" % world if (world > 1 and not host_collectives) else
+                                "no run on more than one GPU has been measured (one-GPU leases only): the N > 1 path is rehearsed with "
+                                "gloo ranks sharing one GPU (tests/test_gpu_bench.py) and 8 CPU ranks (tests/test_cpu_multiview.py)",
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
             "kernel_timing": "hipEvents on the launch stream, single-stream pass right after the timed region",
             "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},
@@ -778,7 +920,8 @@ def main():
         }
         if use_dist:
             out["per_rank_frames_per_s"] = [round(args.steps / float(np.median(b)), 1) for b in per_rank_blocks]
-            out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            out["distributed"] = {"world_size": dist.get_world_size(), "world": dist.get_world_size(), "backend": dist.get_backend(),
+                                  "ranks": devs,
                                   "gather": None if not gather_ms else {
                                       "mode": args.gather_mode,
                                       "exposed_ms_per_block": [round(x, 4) for x in gather_exposed_ms] if gather_exposed_ms else None,

@@ -3,7 +3,7 @@
 # command (FETCH_SIZE, WRITE_SIZE, SQ counters: never combined with trace domains) and the FETCH_SIZE calibration probe.
 # Results under gpurun_out/prof_<tag>/; scripts/update_profiles.py <tag> copies what is judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 EXTRA=${2:-}            # extra bench.py arguments, e.g. "--views-per-call 12"
 MODE=${3:-full}         # "trace": kernel-trace stats only (no PMC passes)
 OUT=$PWD/gpurun_out/prof_$TAG
@@ -44,6 +44,7 @@ python $PWD/bench.py --config 4 --steps 16 --warmup 8 --no-cpu-baseline --no-per
 python $PWD/bench.py --config 3 --steps 16 --warmup 8 --no-cpu-baseline --no-per-view > $OUT/bench_config3.json 2> $OUT/bench_config3.err
 tail -c 300 $OUT/bench_config1.err $OUT/bench_config4.err $OUT/bench_config3.err
 fi
+python $PWD/scripts/compare_ref.py 0 > $OUT/compare_ref.json 2> $OUT/compare_ref.err
 # the round driver's command line (20-step blocks: one 12-view and one 8-view submission each)
 python $PWD/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_shape.json 2> $OUT/bench_driver_shape.err
 python $PWD/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1

@@ -3,10 +3,10 @@ profiles/pmc_traffic.json: per kernel and per launch, the HBM-side bytes from th
 instruction count, and the kernel's average duration in the kernel trace OF THE SAME LEASE, keyed by the workload and call
 shape of the profiled command (bench.py prints `traffic` only for a run with the same key).
 usage: python scripts/update_profiles.py [tag]"""
-import csv, glob, json, os, shutil, sys, collections
+import csv, glob, json, os, shutil, sys, collections, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -86,6 +86,9 @@ for name in ("bench_config1", "bench_config3", "bench_config4"):
             json.dump(json.loads(ls[-1]), open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w"), indent=1)
 out = {
     "key": key,
+    # which kernels the counters belong to: bench.py quotes them only for a tree with the same kernel sources
+    "kernels_sha": bench.get("kernels_sha"),
+    "lease": "gpurun_out/prof_%s (%s)" % (tag, time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(os.path.join(src, "bench.json"))))),
     "sclk_mhz": prof_clk,
     "source": "profiles/%s_bench_rocprofv3_summary.txt: rocprofv3 kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes of "
               "`bench.py --streams 1` and the bench line profiles/%s_bench_line.json, all in one gpurun lease" % (tag, tag),
@@ -131,6 +134,19 @@ if rf:
         rf["valu"] = {"wave_instructions": int(vi), "G_wave_instr_per_s": round(rate / 1e9, 1), "peak_G_wave_instr_per_s": 1228.9,
                       "frac": round(rate / 1e9 / 1228.9, 4), "source": "SQ_INSTS_VALU per launch (same lease); duration measured live"}
     json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
+# context figure: the reference's own kernels (oracle/_ref, hipify-perl build) on the same GPU and view, scripts/compare_ref.py
+cr = os.path.join(src, "compare_ref.json")
+if os.path.exists(cr):
+    ls = [l for l in open(cr).read().splitlines() if l.startswith("{")]
+    if ls:
+        r = json.loads(ls[-1])
+        ref = r.get("ref_strict_ms") or r.get("ref_fast_ms")
+        if ref:
+            json.dump({"label": "the reference's kernels via hipify-perl (oracle/_ref), one view per call: context, not a baseline",
+                       "frames_per_s": round(1e3 / (ref["forward"] + ref["backward"]), 1), "ms": ref, "workload": r.get("workload"),
+                       "W": r.get("W"), "H": r.get("H"), "view": r.get("view"), "lease": out["lease"],
+                       "source": "scripts/compare_ref.py (hipEvents around Reference.bench: 2 warm-up + 5 timed iterations)"},
+                      open(os.path.join(dst, "reference_build.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("key", "fetch_factor", "avg_us")}, indent=1, sort_keys=True))
 print(json.dumps(out["bytes_per_launch"], indent=1, sort_keys=True))
 print(out["valu_wave_instructions_per_launch"])

@@ -20,7 +20,8 @@ def _last_json(out):
 
 
 def test_single_rank_line_has_the_contract_fields(gpu_device):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--drop-in-processes", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -38,6 +39,19 @@ def test_single_rank_line_has_the_contract_fields(gpu_device):
     assert 500 < d["sclk_mhz"]["timed_region"] < 3000 and 500 < d["sclk_mhz"]["stage_pass"] < 3000
     assert d["warmup_effective"]["seconds"] >= 1.0 and d["warmup_effective"]["steps"] >= d["warmup"]
     assert d["config"]["baseline_config"].startswith("configs[2]")
+    # the co-headline: the reference's API as its caller uses it (settings built per call inside the timed loop, one stream, in
+    # order), also from fresh processes; the roofline names the roof its numbers are quoted against AND the one that binds
+    di = d["drop_in"]
+    assert di["frames_per_s"] > 0 and 0 < di["fraction_of_value"] < 1.5 and "simple_raw_render.py:260-278" in di["what"]
+    fp = di["fresh_processes"]
+    assert fp["n"] == 2 and fp["errors"] is None and fp["min"] <= fp["median"] <= fp["max"] and fp["min"] > 0
+    assert d["drop_in_api"]["frames_per_s"]["literal"] == di["frames_per_s"]
+    assert set(("one_stream_in_order", "one_stream_overlap_opt_in", "four_streams")) <= set(d["drop_in_api"]["frames_per_s"])
+    assert d["overlap_of_consecutive_calls"]["on"] is False
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] == rf["hbm_frac"] and "binding_roof" in rf and len(d["kernels_sha"]) == 16
+    assert rf["traffic"] is None or d["kernels_sha"] in rf["traffic_source"]
+    assert "no run on more than one GPU has been measured" in d["multi_gpu_status"]
 
 
 def test_two_ranks_complete(gpu_device):
@@ -114,3 +128,27 @@ def test_config3_shape_two_ranks_p2p_gather_on_one_gpu(gpu_device):
     assert len(d["per_rank_frames_per_s"]) == 2 and min(d["per_rank_frames_per_s"]) > 0
     ga = d["distributed"]["gather"]
     assert ga["mode"] == "p2p" and len(ga["exposed_ms_per_block"]) == 2
+
+
+@pytest.mark.parametrize("config", [3, 4])
+def test_eight_rank_rehearsal_on_one_gpu(config, gpu_device):
+    """BASELINE configs[3] / [4] as the round driver would launch them on an 8-GPU node (`bench.py --gpus 8 --config N`: 8 views, one
+    per rank, frames gathered on rank 0), rehearsed with eight gloo ranks sharing this box's one GPU at a tiny size: every rank
+    issues the same collectives in the same order (or the run hangs), the line carries one rate per rank, where each rank ran and
+    its capped host thread count, and says that no multi-GPU number has been measured."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--device-index", "0",
+                        "--no-cpu-baseline", "--repeats", "1", "--config", str(config), "--no-per-view", "--warmup-seconds", "0.2",
+                        "--workload", "synth-THuman-256", "--points", "6000", "--width", "160", "--height", "96", "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["baseline_config"].startswith("configs[%d]" % config)
+    assert d["config"]["call_shape"]["views_per_call"] == 1          # 8 views over 8 ranks: one view per rank and submission
+    assert len(d["per_rank_frames_per_s"]) == 8 and min(d["per_rank_frames_per_s"]) > 0
+    dd = d["distributed"]
+    assert dd["world"] == 8 and [x["rank"] for x in dd["ranks"]] == list(range(8))
+    assert [x["local_rank"] for x in dd["ranks"]] == list(range(8)) and all(x["device"] == 0 for x in dd["ranks"])
+    cores = os.cpu_count() or 1
+    assert all(1 <= x["host_threads"] <= max(1, cores // 8) for x in dd["ranks"]), dd["ranks"]
+    assert dd["gather"]["collectives"] >= 4 and d["cpu_baseline"] is None
+    assert "no run on more than one GPU has been measured" in d["multi_gpu_status"]

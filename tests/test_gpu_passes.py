@@ -121,9 +121,11 @@ def test_render_passes_equal_the_replay_of_the_reference_callers_trace(gpu_devic
     for name in want:
         assert torch.equal(fused[name], want[name]), name
     assert float((want["rgb"] - 1.0).abs().max()) > 0.05      # the toy cloud is on screen: the images are not pure background
-    # Simple_Render.render: rgb, xyz_w, hitmap (scales as they are, opacity 1); the fused path takes PCML's decoded scales, so the
-    # radius factor is divided out first -- exactly representable here? no: compare the literal path, which has the simple mode
-    prim = rp.simple_primitives(t(G["simple_xyz"]), t(G["simple_rgb"]), sigma=1.5, scale_factor=sf, voxelized=True, offset=offset)
+    # Simple_Render.render: rgb, xyz_w, hitmap (scales as they are, opacity 1) through the literal path's simple mode
+    # (the primitives are formed on the CPU like the fixture's: torch divides by a Python scalar as a multiplication by its
+    # reciprocal on the GPU, one ulp away from the CPU's division in RGB2SH -- torch's arithmetic, not the glue's)
+    prim = {k: v.to(dev) for k, v in rp.simple_primitives(torch.from_numpy(G["simple_xyz"]), torch.from_numpy(G["simple_rgb"]), sigma=1.5,
+                                                          scale_factor=sf, voxelized=True, offset=offset).items()}
     want2 = {name: rp._finish([replay(n_pcml + i * q + j) for j in range(q)], 1, q, h, w, ss)
              for i, name in enumerate(("rgb", "xyz_w", "hitmap"))}
     with torch.no_grad():
