@@ -172,7 +172,7 @@ static int check_params(const gsr_params* p, int V = 1)
     const int64_t gx = (p->W + TILE_X - 1) / TILE_X, gy = (p->H + TILE_Y - 1) / TILE_Y;
     if (gx > 65535 || gy > 65535) return fail(GSR_ERR_INVALID, "[gsr] image too large for 16-bit tile coordinates");
     // backward work items carry the tile in BWD_TILE_BITS bits, and the render grids hold 4 workgroups per tile and view
-    if (gx * gy > (1ll << BWD_TILE_BITS) || (gx * gy / 8 + 1) * 32 * V > 0x7FFFFFFFll)
+    if (gx * gy > (1ll << BWD_TILE_BITS) || (gx * gy / 8 + 1) * 64 * V > 0x7FFFFFFFll)   // (64: the half-quadrant forward's grid)
         return fail(GSR_ERR_INVALID, "[gsr] %lld tiles x %d views: too many for one launch", (long long)(gx * gy), V);
     return GSR_OK;
 }
@@ -685,6 +685,7 @@ __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long lon
 #endif
 
 long long gsr_d2h_count(void) { return gsr::g_d2h_count.load(); }
+int gsr_set_forward_half_views(int views) { return gsr::forward_half_views(views); }
 
 int gsr_last_list_pairs(int64_t* out, int V)
 {

@@ -26,6 +26,9 @@
 // k_render_forward<NX>, NX = 4 or 8: the same walk also composites NX extra per-Gaussian channels with the colour's alphas
 // (gsr_forward_batch_channels: the reference's callers render world xyz, a hit map and normals as three more full passes,
 // simple_raw_render.py:410-524).  The extra values ride in the pair records next to the colour; NX = 0 is the plain kernel.
+#include <atomic>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -530,6 +533,280 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     }
 }
 
+// ---- half-quadrant mode: the forward of SINGLE-VIEW submissions -------------------------------------------------------------
+// A single view's launch ends on a dozen waves that evaluate 500-650 pairs each, alone on their SIMDs, one instruction per ~10
+// cycles, while the chip is a third occupied: what matters there is the number of instructions on a deep
+// walk's critical path, not throughput.  In this mode a wave owns HALF a quadrant (8 x 4 pixels; eight single-wave workgroups
+// per tile) and keeps its pixels TWICE: lanes 0-31 and lanes 32-63 hold the same 32 pixels.  A step covers FOUR consecutive
+// surviving entries: the lower half of the wave evaluates alpha for entries 0 and 1 (one staged pair record), the upper half for
+// entries 2 and 3 (the next record) -- the expensive part, 60 of a pair's 90 instructions, is done for four entries in the time
+// of two -- then two v_permlane32_swap hand every lane all four alphas and both halves run the same blend of the four entries in
+// order (redundantly: identical registers in both halves, no further exchange).  Per (pixel, entry) the arithmetic is the
+// 8 x 8 kernel's, term for term: power, exp, alpha, T (1 - alpha), (c alpha) T, the 1/255 and 1e-4 tests, in list order; the
+// images, final_T and n_contrib are bit-identical (tests compare both modes with the reference build).  Twice the waves gather and
+// cull the same 64 entries per round, which is why batches (throughput-bound: the 12-view launch keeps 87 % of the wave slots
+// busy) stay on the 8 x 8 kernel.
+__device__ __forceinline__ void swap_halves2(float& a_lo, float& a_hi, float& b_lo, float& b_hi)
+{
+    // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Called with x == y == v (two registers holding the same
+    // per-lane value): afterwards x holds the LOWER half's v in all 64 lanes (lane i and lane i + 32 both have lane i's), y the upper
+    // half's.  hipcc pads no wait states inside asm: the statement carries its own s_nop 1 in front (VALU write -> permlane
+    // swap read: 2 wait states on gfx950) and behind (swap write -> VALU read).
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi));
+}
+
+__global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
+{
+    constexpr int PW = PAIR_WORDS;
+    // workgroup b runs on XCD b % 8: the eight half-quadrants of one tile are b, b + 8, ..., b + 56 (one L2 fetch of list and records);
+    // groups of 64 workgroups (8 tiles x 8 halves) are dealt to the views round-robin like the 8 x 8 kernel's groups of 32
+    const uint32_t group = blockIdx.x >> 6;
+    const uint32_t view = group % a.V;
+    const uint32_t order_slot = (group / a.V) * 8u + (blockIdx.x & 7u);
+    if (order_slot >= (uint32_t)a.num_tiles) return;
+    a.ranges = at_view(a.ranges, a.iv_stride, view);
+    a.tile_order = at_view(a.tile_order, a.iv_stride, view);
+    a.final_T = at_view(a.final_T, a.iv_stride, view);
+    a.n_contrib = at_view(a.n_contrib, a.iv_stride, view);
+    a.tile_need = at_view(a.tile_need, a.iv_stride, view);
+    a.accum = at_view(a.accum, a.iv_stride, view);
+    a.point_list = at_view(a.point_list, a.b_stride, view);
+    if (a.ckpt) a.ckpt = at_view(a.ckpt, a.b_stride, view);
+    a.splat = at_view(a.splat, a.g_stride, view);
+    a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
+    const uint32_t tile = a.tile_order[order_slot];
+    const uint32_t sb = (blockIdx.x >> 3) & 7u, q = sb >> 1, hf = sb & 1u;
+    const uint32_t lane = threadIdx.x, pl = lane & 31u, eg = lane >> 5;   // pixel of the half, entry group
+    const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
+    const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u + hf * 4u;
+    const uint32_t px = x0 + (pl & 7u), py = y0 + (pl >> 3);
+    const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
+    const float pixf_x = (float)px, pixf_y = (float)py;
+    const float x0f = (float)x0, y0f = (float)y0;
+    float bx0 = x0f, by0 = y0f, bx1 = x0f + 7.f, by1 = y0f + 3.f;
+
+    __shared__ __attribute__((aligned(16))) float stage[35 * PW];   // 32 pairs + a zero pair behind an odd count + read-ahead
+
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    float T = 1.0f;
+    f32x2 C01 = {0.f, 0.f};
+    float C2 = 0.f;
+    uint32_t last_contributor = 0;
+    uint32_t stop_at = 0;
+    bool crossed = false;
+    bool done = !inside;
+    bool all_done = __all(done);
+    if (!all_done) {
+        int ax, ay, bx, by;
+        live_box(__ballot(!done) & 0xFFFFFFFFull, ax, ay, bx, by);   // (both halves of the wave hold the same 32 pixels)
+        bx0 = x0f + (float)ax; by0 = y0f + (float)ay; bx1 = x0f + (float)bx; by1 = y0f + (float)by;
+    }
+
+    if (!all_done && total > 0) {
+        const uint32_t* plist = a.point_list + range.x;
+        const int last = total - 1;
+        f32x4 c0, c1, n0, n1;
+        float c2b, n2b;
+        uint32_t id_cur, id_nxt, id_nn;
+        {
+            prefetch4(id_cur, plist + ((int)lane < total ? (int)lane : last));
+            prefetch4(id_nxt, plist + (64 + (int)lane < total ? 64 + (int)lane : last));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(id_cur), "+v"(id_nxt)::"memory");
+            const Splat* sp = a.splat + id_cur;
+            prefetch16(c0, &sp->q0);
+            prefetch16(c1, &sp->q1);
+            prefetch4f(c2b, &sp->q2);
+            retire_prefetch(c0, c1, c2b, id_nxt);
+        }
+        for (int base = 0; base < total; base += 64) {
+            {
+                const Splat* sp = a.splat + id_nxt;
+                prefetch16(n0, &sp->q0);
+                prefetch16(n1, &sp->q1);
+                prefetch4f(n2b, &sp->q2);
+                const int i2 = base + 128 + (int)lane;
+                prefetch4(id_nn, plist + (i2 < total ? i2 : last));
+            }
+            // the backward's slice-boundary state: pixel (x, y) of the quadrant sits at index 8 y + x = 32 hf + pl, as in the 8 x 8 kernel
+            if (a.ckpt != nullptr && base != 0 && (base & ((1 << a.chunk_shift) - 1)) == 0 && (base >> a.chunk_shift) < BWD_MAX_CHUNKS) {
+                const size_t slot = (size_t)(range.x >> a.chunk_shift) + (size_t)(base >> a.chunk_shift);
+                if (eg == 0) a.ckpt[slot * 256 + q * 64 + hf * 32u + pl] = make_float4(T, C01.x, C01.y, C2);
+                crossed = true;
+            }
+            const bool valid = base + (int)lane < total;
+            const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx0, by0, bx1, by1);
+            const uint64_t mask = __ballot(touch);
+            if (mask != 0) {
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t nsurv = (uint32_t)__popcll(mask);
+                const int npairs = (int)((nsurv + 1u) >> 1);
+                if (touch) {
+                    float* p = stage + (slot >> 1) * PW + (slot & 1u);
+                    p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
+                    float* pc = stage + (slot >> 1) * PW + 12 + 2 * (slot & 1u);
+                    pc[0] = c1.z; pc[1] = c1.w;
+                    p[16] = c2b;
+                    const uint32_t my_pos = (uint32_t)(base + (int)lane + 1);
+                    uint32_t* pp = (uint32_t*)p;
+                    pp[18] = my_pos;
+                    if (slot + 1 == nsurv && (slot & 1u) == 0) {   // odd count: the partner is a copy with opacity 0
+                        p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
+                        pc[2] = c1.z; pc[3] = c1.w;
+                        p[17] = c2b;
+                        pp[19] = my_pos;
+                    }
+                }
+                // an odd number of PAIRS: the upper half's record of the last step is a pair of opacity 0 (alpha 0: never counted)
+                if ((npairs & 1) && lane < (uint32_t)PW) stage[npairs * PW + lane] = 0.f;
+                const int nsteps = (npairs + 1) >> 1;
+                // a step's seven LDS reads: the half's own pair record (alpha of two entries) and, from both records of the step,
+                // colours and list positions.  The next step's are issued before the current one is evaluated (two register sets
+                // taking turns, like the 8 x 8 kernel's pairs); the read past the last step lands in the spare records.
+                struct StepRec {
+                    f32x4 xy, ab, co, rgA, rgB;
+                    f32x2 bA, bB;
+                    uint2 posA, posB;
+                };
+                auto load_step = [&](int st) {
+                    StepRec r;
+                    const float* po = stage + (2 * st + (int)eg) * PW;
+                    const float* pa = stage + (2 * st) * PW;
+                    r.xy = *(const f32x4*)(po + 0);
+                    r.ab = *(const f32x4*)(po + 4);
+                    r.co = *(const f32x4*)(po + 8);
+                    r.rgA = *(const f32x4*)(pa + 12);
+                    r.rgB = *(const f32x4*)(pa + PW + 12);
+                    r.bA = *(const f32x2*)(pa + 16);
+                    r.bB = *(const f32x2*)(pa + PW + 16);
+                    r.posA = *(const uint2*)(pa + 18);
+                    r.posB = *(const uint2*)(pa + PW + 18);
+                    return r;
+                };
+                auto eval_step = [&](const StepRec& r) {
+                    const f32x4 rgA = r.rgA, rgB = r.rgB;
+                    const f32x2 bA = r.bA, bB = r.bB;
+                    const uint2 posA = r.posA, posB = r.posB;
+                    const f32x2 X = {r.xy.x, r.xy.y}, Y = {r.xy.z, r.xy.w}, A2 = {r.ab.x, r.ab.y}, B2 = {r.ab.z, r.ab.w};
+                    const f32x2 C2p = {r.co.x, r.co.y}, O2 = {r.co.z, r.co.w};
+                    const f32x2 dx = X - pixf_x, dy = Y - pixf_y;
+                    const f32x2 power = -0.5f * (A2 * dx * dx + C2p * dy * dy) - B2 * dx * dy;
+                    const f32x2 al = O2 * exp_nonpos2(power);
+                    const float alpha0 = fminf(0.99f, al.x), alpha1 = fminf(0.99f, al.y);
+                    // an entry counts for a pixel that is still live when the STEP begins; pixels that stop inside the step are
+                    // handled by the exact path below.  alpha >= 1/255 > 0 for every counted entry, so "counted" <=> e != 0.
+                    float ea = (!done && !(power.x > 0.0f) && !(alpha0 < 1.0f / 255.0f)) ? alpha0 : 0.f;
+                    float eb = (!done && !(power.y > 0.0f) && !(alpha1 < 1.0f / 255.0f)) ? alpha1 : 0.f;
+                    float e0 = ea, e2 = ea, e1 = eb, e3 = eb;
+                    swap_halves2(e0, e2, e1, e3);   // e0 / e1: the lower half's two entries, e2 / e3: the upper half's, in every lane
+                    const float T1 = T * (1 - e0), T2 = T1 * (1 - e1), T3 = T2 * (1 - e2), T4 = T3 * (1 - e3);
+                    if (!__any(T4 < 0.0001f)) {
+                        // no pixel of the wave stops inside the step (T never increases, every live pixel has T >= 1e-4)
+                        C01 += f32x2{rgA.x, rgA.y} * e0 * T;
+                        C2 += bA.x * e0 * T;
+                        C01 += f32x2{rgA.z, rgA.w} * e1 * T1;
+                        C2 += bA.y * e1 * T1;
+                        C01 += f32x2{rgB.x, rgB.y} * e2 * T2;
+                        C2 += bB.x * e2 * T2;
+                        C01 += f32x2{rgB.z, rgB.w} * e3 * T3;
+                        C2 += bB.y * e3 * T3;
+                        last_contributor = e0 != 0.f ? posA.x : last_contributor;
+                        last_contributor = e1 != 0.f ? posA.y : last_contributor;
+                        last_contributor = e2 != 0.f ? posB.x : last_contributor;
+                        last_contributor = e3 != 0.f ? posB.y : last_contributor;
+                        T = T4;
+                    } else {
+                        // some pixel stops inside these four entries: the reference's sequence, entry by entry.  s: the entry
+                        // would take T below 1e-4 -> the pixel stops and the entry is NOT blended; b: the entry is blended.
+                        bool stopped = false;
+                        const float es[4] = {e0, e1, e2, e3};
+                        const f32x2 rgs[4] = {f32x2{rgA.x, rgA.y}, f32x2{rgA.z, rgA.w}, f32x2{rgB.x, rgB.y}, f32x2{rgB.z, rgB.w}};
+                        const float bs[4] = {bA.x, bA.y, bB.x, bB.y};
+                        const uint32_t ps[4] = {posA.x, posA.y, posB.x, posB.y};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool c = es[k] != 0.f && !stopped;
+                            const float Tn = T * (1 - es[k]);
+                            const bool sk = c && (Tn < 0.0001f);
+                            const bool bk = c && !sk;
+                            const float be = bk ? es[k] : 0.f;
+                            C01 += rgs[k] * be * T;
+                            C2 += bs[k] * be * T;
+                            T = T * (1 - be);
+                            last_contributor = bk ? ps[k] : last_contributor;
+                            stop_at = sk ? ps[k] : stop_at;
+                            stopped = stopped || sk;
+                        }
+                        done = done || stopped;
+                        const uint64_t live = __ballot(!done) & 0xFFFFFFFFull;
+                        all_done = live == 0;
+                        if (!all_done) {
+                            int ax, ay, bx, by;
+                            live_box(live, ax, ay, bx, by);
+                            bx0 = x0f + (float)ax; by0 = y0f + (float)ay; bx1 = x0f + (float)bx; by1 = y0f + (float)by;
+                        }
+                    }
+                };
+                int step = 0;
+                StepRec ra = load_step(0), rb;
+                for (;;) {
+                    rb = load_step(step + 1);
+                    eval_step(ra);
+                    if (all_done || ++step >= nsteps) break;
+                    ra = load_step(step + 1);
+                    eval_step(rb);
+                    if (all_done || ++step >= nsteps) break;
+                }
+            }
+            retire_prefetch(n0, n1, n2b, id_nn);
+            if (all_done) break;
+            c0 = n0; c1 = n1; c2b = n2b;
+            id_cur = id_nxt;
+            id_nxt = id_nn;
+        }
+    }
+    {
+        uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(need, d, 64);
+            need = need > o ? need : o;
+        }
+        if (lane == 0 && need != 0) atomicMax(&a.tile_need[tile], need);
+    }
+    if (inside && eg == 0) {
+        const size_t pix = (size_t)py * a.W + px, N = (size_t)a.W * a.H;
+        a.final_T[pix] = T;
+        a.n_contrib[pix] = last_contributor;
+        a.out_color[pix] = C01.x + T * a.bg[0];
+        a.out_color[N + pix] = C01.y + T * a.bg[1];
+        a.out_color[2 * N + pix] = C2 + T * a.bg[2];
+        if (crossed) {
+            a.accum[pix] = C01.x;
+            a.accum[N + pix] = C01.y;
+            a.accum[2 * N + pix] = C2;
+        }
+    }
+}
+
+// views per submission up to which the forward runs in half-quadrant mode: GSR_FWD_HALF_V in the environment when the library is
+// first used (default 1; 0: never), or gsr_set_forward_half_views() (tests compare the two kernels in one process)
+static std::atomic<int> g_fwd_half_v{-1};
+int forward_half_views(int set)
+{
+    if (set >= 0) g_fwd_half_v.store(set);
+    int v = g_fwd_half_v.load();
+    if (v < 0) {
+        const char* e = getenv("GSR_FWD_HALF_V");
+        v = e ? atoi(e) : 1;
+        if (v < 0) v = 0;
+        g_fwd_half_v.store(v);
+    }
+    return v;
+}
+
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
                           bool with_ckpt, const ExtraChannels* X)
 {
@@ -560,6 +837,8 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
         a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out; a.extra_vstride = X->view_stride;
         if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
         else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
+    } else if (B.V <= forward_half_views(-1)) {
+        hipLaunchKernelGGL(k_render_forward_half, dim3((unsigned)div_up(T, 8) * 64u * (unsigned)B.V), dim3(64), 0, L.stream, a);
     } else {
         hipLaunchKernelGGL(k_render_forward<0>, grid, dim3(64), 0, L.stream, a);
     }

@@ -34,7 +34,7 @@ class GsrParams(C.Structure):
 SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
            "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
-           "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs")
+           "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs", "gsr_set_forward_half_views")
 
 GSR_RETRY = 1
 
@@ -83,6 +83,8 @@ def _load():
     lib.gsr_query.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, _fp, C.c_size_t, _fp, C.c_int64, _fp, C.c_size_t, _fp]
     lib.gsr_set_profiling.restype = None
     lib.gsr_set_profiling.argtypes = [C.c_int]
+    lib.gsr_set_forward_half_views.restype = C.c_int
+    lib.gsr_set_forward_half_views.argtypes = [C.c_int]
     lib.gsr_get_profile.restype = C.c_int
     lib.gsr_get_profile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.gsr_selftest.restype = C.c_int

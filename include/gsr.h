@@ -238,6 +238,12 @@ int gsr_selftest(gsr_stream_t stream);
  * copy command in the stream.  For tests that guard the call path against host stalls. */
 long long gsr_d2h_count(void);
 
+/* Tuning / test hook: submissions of up to `views` views run the forward render in half-quadrant mode (csrc/render_fwd.hip: a wave
+ * owns 8 x 4 pixels twice and blends four list entries per step -- a shorter critical path for the deep walks a single view's launch
+ * ends on; images, final_T and n_contrib are bit-identical in both modes).  Default 1 (GSR_FWD_HALF_V in the environment), 0 = the
+ * 8 x 8 kernel always; views < 0 only queries.  Returns the value in force. */
+int gsr_set_forward_half_views(int views);
+
 const char* gsr_last_error(void);
 const char* gsr_version(void);
 

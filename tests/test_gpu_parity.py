@@ -186,3 +186,29 @@ def test_fma_contraction_moves_few_decisions(gpu_device):
           % (moved_radii, s.P, moved_R, err.max(), int((err.max(axis=0) > 1e-4).sum())))
     assert moved_radii <= max(2, s.P // 5000)
     assert (err.max(axis=0) > 1e-4).mean() < 5e-3
+
+
+@pytest.mark.parametrize("name", ["capsule_circle", "opaque_early_stop", "deep_stack", "big_splats", "voxel_ties", "culled_mix"])
+def test_half_quadrant_forward_equals_the_8x8_kernel(name, gpu_device):
+    """Single-view submissions run the forward render in half-quadrant mode (csrc/render_fwd.hip k_render_forward_half: 8 x 4 pixels
+    per wave, four list entries per step), batches on the 8 x 8 kernel.  Same scene through both kernels in one process: image,
+    final_T, n_contrib, tile_need bit-identical, gradients of the backward that follows (it reads the forward's slice-boundary
+    states) identical up to atomic order; and against the reference build."""
+    from diff_gaussian_rasterization import _native as N
+    s = build_scene(name)
+    dL = seeded_dL(s)
+    was = N.lib.gsr_set_forward_half_views(-1)
+    try:
+        assert N.lib.gsr_set_forward_half_views(0) == 0
+        a, ga = run_product(s, gpu_device, dL_dpix=dL)
+        assert N.lib.gsr_set_forward_half_views(1) == 1
+        b, gb = run_product(s, gpu_device, dL_dpix=dL)
+    finally:
+        N.lib.gsr_set_forward_half_views(was)
+    for k in ("out_color", "final_T", "n_contrib", "radii", "vals", "ranges"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    r = _ref("strict").forward(s)
+    assert b["out_color"].tobytes() == r["out_color"].tobytes() and b["final_T"].tobytes() == r["final_T"].tobytes()
+    for k in ga:
+        if ga[k].size:
+            assert np.abs(ga[k].astype(np.float64) - gb[k]).max() <= 2e-5 * (np.abs(ga[k]).max() + 1e-30), k
