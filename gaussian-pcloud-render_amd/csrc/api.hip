@@ -686,6 +686,7 @@ __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long lon
 
 long long gsr_d2h_count(void) { return gsr::g_d2h_count.load(); }
 int gsr_set_forward_half_views(int views) { return gsr::forward_half_views(views); }
+int gsr_set_backward_moments(int mode) { return gsr::backward_subquadrant_moments(mode); }
 
 int gsr_last_list_pairs(int64_t* out, int V)
 {

@@ -322,6 +322,7 @@ struct ExtraChannels {
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
                           bool with_ckpt, const ExtraChannels* X = nullptr);
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix);
+int backward_subquadrant_moments(int set);   // render_bwd.hip: set >= 0 stores; 1 = moments about the sub-quadrant centres
 int forward_half_views(int set);   // render_fwd.hip: set >= 0 stores; returns the views per submission up to which the half-quadrant forward runs
 int selftest_mm(hipStream_t stream, float* d_scratch256);   // the matrix-core pixel contraction of the render backward
 #ifdef GSR_STATS

@@ -26,6 +26,9 @@
 // (oracle: orc_render_backward_fp64) the colour and opacity gradients are as accurate as the reference build's, the
 // mean2D / conic gradients 1.8x / 4x its error at the median (3e-7 .. 9e-7 of max|g|): the moments are rounded once per
 // quadrant where the reference rounds every pixel's product on its own (profiles/r04_bwd_accuracy.txt).
+#include <atomic>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "tile_cull.hpp"
 
@@ -124,13 +127,19 @@ __device__ __forceinline__ uint32_t mm_pos(uint32_t lane)
     const uint32_t x = lane & 7u, y = lane >> 3;
     return 16u * (y >> 1) + 4u * ((x & 1u) + 2u * (y & 1u)) + (x >> 1);
 }
+// SUBQ: the basis polynomials of a K step are taken about the centre of the 4 x 4 SUB-QUADRANT the step's 2 x 2 pixel block lies in
+// (|c| <= 1.5 instead of <= 3.5) and the steps of each sub-quadrant go to an accumulator of their own (mm_contract4): the moments a
+// splat is shifted by are then at most ~2 pixels from it in the sub-quadrant that holds most of its weight, and the float32
+// rounding of the moments -- (b / sigma)^2 relative to the second moment about the splat itself -- drops by the square of that ratio.
+template <bool SUBQ>
 __device__ __forceinline__ void mm_basis(float (&am)[16], uint32_t lane)
 {
     const uint32_t i = lane & 15u, k = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
         // step s = 4 m + r, operand lane group k: pixel x = 2 r + (k & 1), y = 2 m + (k >> 1)
-        const float cx = (float)(2u * (uint32_t)(s & 3) + (k & 1u)) - 3.5f, cy = (float)(2u * (uint32_t)(s >> 2) + (k >> 1)) - 3.5f;
+        const uint32_t x = 2u * (uint32_t)(s & 3) + (k & 1u), y = 2u * (uint32_t)(s >> 2) + (k >> 1);
+        const float cx = SUBQ ? (float)(x & 3u) - 1.5f : (float)x - 3.5f, cy = SUBQ ? (float)(y & 3u) - 1.5f : (float)y - 3.5f;
         const uint32_t c = i & 3u;
         const float f = c == 0 ? 1.f : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
         am[s] = i < 12u ? f : 0.f;
@@ -163,6 +172,24 @@ __device__ __forceinline__ f32x4 mm_contract(const float* mrow, const float (&am
         if ((blocks >> (16 * m + 6)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 3], b.w, acc, 0, 0, 0);
     }
     return acc;
+}
+
+// four accumulators, one per 4 x 4 sub-quadrant sq = 2 (m >> 1) + (r >> 1) (see mm_basis<true>); same sixteen steps, same skipping
+__device__ __forceinline__ void mm_contract4(const float* mrow, const float (&am)[16], uint32_t lane, unsigned long long blocks, f32x4 (&acc)[4])
+{
+    const f32x4* rp = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const f32x4 b = rp[4 * m];
+        f32x4& aL = acc[2 * (m >> 1)];
+        f32x4& aR = acc[2 * (m >> 1) + 1];
+        if ((blocks >> (16 * m + 0)) & 1ull) aL = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 0], b.x, aL, 0, 0, 0);
+        if ((blocks >> (16 * m + 2)) & 1ull) aL = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 1], b.y, aL, 0, 0, 0);
+        if ((blocks >> (16 * m + 4)) & 1ull) aR = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 2], b.z, aR, 0, 0, 0);
+        if ((blocks >> (16 * m + 6)) & 1ull) aR = __builtin_amdgcn_mfma_f32_16x16x4f32(am[4 * m + 3], b.w, aR, 0, 0, 0);
+    }
 }
 
 #ifdef GSR_BWD_EMUL
@@ -203,7 +230,7 @@ __global__ void k_selftest_mm(float* out256)
     __shared__ __attribute__((aligned(16))) float mrow[16 * MM_STRIDE];
     const uint32_t lane = threadIdx.x;
     float am[16];
-    mm_basis(am, lane);
+    mm_basis<false>(am, lane);
     // "dL_dpixel" of pixel p, channel c: ((p + 2 c) % 5) - 2
     const uint32_t pos = mm_pos(lane);
     for (int c = 0; c < 3; c++) mrow[c * MM_STRIDE + pos] = (float)((int)((lane + 2u * c) % 5u) - 2);
@@ -301,6 +328,7 @@ struct RenderBwdArgs {
 
 // five waves per SIMD: 96 registers (the accumulator in VGPRs, five values of the item set-up spilled outside the hot
 // loops); the loop runs at ~70 % of the vector pipe with four waves, a fifth is worth 2.6 %
+template <bool SUBQ>
 __attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     __shared__ float dpx_raster[3 * 64];
 #endif
     float am[16];                                                          // A operands of the 16 K steps (basis)
-    mm_basis(am, threadIdx.x);
+    mm_basis<SUBQ>(am, threadIdx.x);
     const uint32_t mm_p = mm_pos(threadIdx.x);                              // this lane's pixel in a row
     // what this lane does with its four accumulator values after a batch's contraction (see mm_basis): g < 3 on q columns,
     // g = 3 on u columns
@@ -644,6 +672,31 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
             // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
+            float o1, o2, o3;
+            if constexpr (SUBQ) {
+                // moments about the four sub-quadrant centres (quadrant centre -+2 in x and y), each shifted to the splat centre on
+                // its own and then added: sum q dx^2 etc. lose (b / sigma)^2 of their bits with b the distance to the SUB-quadrant
+                // centre, and the sub-quadrants far from the splat carry little weight
+                f32x4 acc4[4];
+                mm_contract4(mrow, am, lane, hit_blocks, acc4);
+                const float bx = eX - mm_sx, by = eY - mm_sy;
+                const float bxs[2] = {bx + 2.f, bx - 2.f}, bys[2] = {by + 2.f, by - 2.f};
+                float S1 = 0.f, Dx = 0.f, Dy = 0.f, t2 = 0.f, Ay = 0.f, Az = 0.f;
+#pragma unroll
+                for (int sq = 0; sq < 4; sq++) {
+                    const float bxq = bxs[sq & 1], byq = bys[sq >> 1];
+                    const float s1 = acc4[sq].x, sx = acc4[sq].y, sy = acc4[sq].z, v3 = acc4[sq].w;
+                    const float dxq = __builtin_fmaf(bxq, s1, -sx), dyq = __builtin_fmaf(byq, s1, -sy);
+                    const float t2q = __builtin_fmaf(mm_g == 0 ? bxq : byq, mm_g == 2u ? dyq : dxq,
+                                                     __builtin_fmaf(-(mm_g == 2u ? byq : bxq), mm_g == 0 ? sx : sy, v3));
+                    S1 += s1; Dx += dxq; Dy += dyq; t2 += t2q; Ay += sx; Az += sy;
+                }
+                o1 = -0.5f * cO * t2;                                                        // conic x | y | w
+                o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                         // mean2D x | y
+                if (mm_g == 2u) o2 = S1;                                                     // opacity
+                if (mm_u) { o1 = S1; o2 = Ay; }                                              // colour r, g (row 3, u columns: sums of rows 12, 13)
+                o3 = Az;                                                                     // colour b
+            } else {
 #ifdef GSR_BWD_EMUL
             const f32x4 acc = mm_contract_emul(mrow, dpx_raster, lane);
 #else
@@ -655,8 +708,8 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const double bxd = (double)eX - (double)mm_sx, byd = (double)eY - (double)mm_sy;
             const double Dxd = bxd * S1 - Sx, Dyd = byd * S1 - Sy;
             const double t2d = (mm_g == 0 ? bxd : byd) * (mm_g == 2u ? Dyd : Dxd) - (mm_g == 2u ? byd : bxd) * (mm_g == 0 ? Sx : Sy) + V3;
-            float o1 = (float)(-0.5 * cO * t2d);
-            float o2 = (float)(((double)cO * mm_dd) * ((double)cP * Dxd + (double)cQ * Dyd));
+            o1 = (float)(-0.5 * cO * t2d);
+            o2 = (float)(((double)cO * mm_dd) * ((double)cP * Dxd + (double)cQ * Dyd));
 #else
             const float bx = eX - mm_sx, by = eY - mm_sy;             // splat centre - quadrant centre
             const float Dx = __builtin_fmaf(bx, S1, -Sx), Dy = __builtin_fmaf(by, S1, -Sy);   // sum q dx, sum q dy
@@ -664,12 +717,13 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             // sum q dy^2 = by Dy - by Sy + Syy
             const float t2 = __builtin_fmaf(mm_g == 0 ? bx : by, mm_g == 2u ? Dy : Dx,
                                             __builtin_fmaf(-(mm_g == 2u ? by : bx), mm_g == 0 ? Sx : Sy, V3));
-            float o1 = -0.5f * cO * t2;                                                  // conic x | y | w
-            float o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                   // mean2D x | y
+            o1 = -0.5f * cO * t2;                                                  // conic x | y | w
+            o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                   // mean2D x | y
 #endif
             if (mm_g == 2u) o2 = S1;                                                     // opacity
             if (mm_u) { o1 = acc.x; o2 = acc.y; }                                        // colour r, g (row 3, u columns)
-            const float o3 = acc.z;                                                      // colour b
+            o3 = acc.z;                                                                  // colour b
+            }
             // Hand the second and third values to idle lanes of the same 16-lane row, so that the nine values of an entry
             // sit in nine lanes and ONE atomic instruction serves four entries (the nine addresses of an entry fall into
             // one 64-B record: atomics are priced per line touched).  vA: entries 0..3 of the batch, vB: entries 4..7.
@@ -723,6 +777,22 @@ int debug_bwd_stats(unsigned long long* out8, int reset)
 }
 #endif
 
+// Which moments the contraction takes: 0 (default) about the quadrant centre, 1 about the four sub-quadrant centres (mean2D / conic
+// sums at the reference build's accuracy, for more flush arithmetic).  GSR_BWD_SUBQ in the environment when the library is first
+// used, or gsr_set_backward_moments() (tests, scripts/bwd_accuracy.py).
+static std::atomic<int> g_bwd_subq{-1};
+int backward_subquadrant_moments(int set)
+{
+    if (set >= 0) g_bwd_subq.store(set ? 1 : 0);
+    int v = g_bwd_subq.load();
+    if (v < 0) {
+        const char* e = getenv("GSR_BWD_SUBQ");
+        v = (e && atoi(e) != 0) ? 1 : 0;
+        g_bwd_subq.store(v);
+    }
+    return v;
+}
+
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix)
 {
     RenderBwdArgs a;
@@ -755,7 +825,10 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     const int64_t fill = div_up(GSR_BWD_FILL, B.V);        // 4096 groups x 32 single-wave workgroups = 25 per wave slot (measured: 1280 / 2048 / 2560 / 4096 / 8192 groups -> 0.216 / 0.213 / 0.211 / 0.210 / 0.221 ms per view)
     if (groups > fill) groups = fill;
     if (groups < 8) groups = 8;
-    hipLaunchKernelGGL(k_render_backward, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
+    if (backward_subquadrant_moments(-1))
+        hipLaunchKernelGGL(k_render_backward<true>, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
+    else
+        hipLaunchKernelGGL(k_render_backward<false>, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
     return check_launch(L, "render_backward");
 }
 

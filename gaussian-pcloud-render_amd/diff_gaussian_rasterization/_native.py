@@ -34,7 +34,8 @@ class GsrParams(C.Structure):
 SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr_binning_bytes", "gsr_forward_batch", "gsr_forward_stage1",
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
            "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
-           "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs", "gsr_set_forward_half_views")
+           "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs", "gsr_set_forward_half_views",
+           "gsr_set_backward_moments")
 
 GSR_RETRY = 1
 
@@ -85,6 +86,8 @@ def _load():
     lib.gsr_set_profiling.argtypes = [C.c_int]
     lib.gsr_set_forward_half_views.restype = C.c_int
     lib.gsr_set_forward_half_views.argtypes = [C.c_int]
+    lib.gsr_set_backward_moments.restype = C.c_int
+    lib.gsr_set_backward_moments.argtypes = [C.c_int]
     lib.gsr_get_profile.restype = C.c_int
     lib.gsr_get_profile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.gsr_selftest.restype = C.c_int
@@ -647,6 +650,13 @@ class ClockProbe:
 def selftest(device):
     with torch.cuda.device(device):
         _check(lib.gsr_selftest(torch.cuda.current_stream(device).cuda_stream))
+
+
+def set_backward_moments(mode):
+    """0 (default): the render backward's pixel contraction takes second moments about the 8 x 8 quadrant centre; 1: about the four
+    4 x 4 sub-quadrant centres (mean2D / conic sums 1.25x / 1.9x the reference build's rounding error instead of 1.9x / 4x, for +8 %
+    of that kernel's time; include/gsr.h gsr_set_backward_moments, GSR_BWD_SUBQ).  Returns the mode in force."""
+    return int(lib.gsr_set_backward_moments(int(mode)))
 
 
 def set_profiling(on):

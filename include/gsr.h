@@ -244,6 +244,12 @@ long long gsr_d2h_count(void);
  * 8 x 8 kernel always; views < 0 only queries.  Returns the value in force. */
 int gsr_set_forward_half_views(int views);
 
+/* Accuracy / speed switch of the render backward's pixel contraction: 0 (default; GSR_BWD_SUBQ=0) second moments about the 8 x 8
+ * quadrant centre; 1 about the centres of its four 4 x 4 sub-quadrants, each shifted to the splat centre on its own: the mean2D /
+ * conic sums then carry the reference build's rounding error instead of 1.9x / 4x of it, for more arithmetic
+ * per batch of eight entries.  mode < 0 only queries.  Returns the value in force. */
+int gsr_set_backward_moments(int mode);
+
 const char* gsr_last_error(void);
 const char* gsr_version(void);
 

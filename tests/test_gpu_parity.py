@@ -212,3 +212,59 @@ def test_half_quadrant_forward_equals_the_8x8_kernel(name, gpu_device):
     for k in ga:
         if ga[k].size:
             assert np.abs(ga[k].astype(np.float64) - gb[k]).max() <= 2e-5 * (np.abs(ga[k]).max() + 1e-30), k
+
+
+def test_subquadrant_moments_mode_is_correct_and_more_accurate(oracle, gpu_device):
+    """gsr_set_backward_moments(1): the render backward's pixel contraction takes its moments about the four sub-quadrant centres
+    (csrc/render_bwd.hip, k_render_backward<true>).  Gradients stay inside the bars against the reference build on the parity
+    scenes, and against the float64 render backward (the oracle's arbiter) the mean2D / conic sums are closer than in the default
+    mode (moments about the quadrant centre) over a set of fuzz cases with sub-pixel to tile-sized splats."""
+    import torch
+    import test_gpu_fuzz as F
+    from diff_gaussian_rasterization import _native as N
+    ref = _ref("strict")
+    was = N.lib.gsr_set_backward_moments(-1)
+    try:
+        assert N.lib.gsr_set_backward_moments(1) == 1
+        for name in ("capsule_circle", "random_aniso", "big_splats", "deep_stack"):
+            s = build_scene(name)
+            dL = seeded_dL(s)
+            _, gr = ref.forward_backward(s, dL)
+            _, gp = run_product(s, gpu_device, dL_dpix=dL)
+            gr = dict(gr)
+            gr["dL_dopacity"] = gr["dL_dopacity"].reshape(gp["dL_dopacity"].shape)
+            _check_grads(gp, gr, name + " (sub-quadrant moments vs ref)")
+        err = {0: {"mean2D": [], "conic": []}, 1: {"mean2D": [], "conic": []}}
+        for c in range(0, 48):
+            s, _ = F._case(c)
+            if s.P == 0:
+                continue
+            dL = seeded_dL(s, seed=77 + c)
+            _, go = oracle.forward_backward(s, dL, exact=True)
+            want = dict(mean2D=np.asarray(go["exact"]["dL_dmean2D"], np.float64)[:, :2],
+                        conic=np.asarray(go["exact"]["dL_dconic"], np.float64)[:, [0, 1, 3]])
+            if np.abs(want["conic"]).max() == 0:
+                continue
+
+            def t(a):
+                return torch.empty(0) if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device)
+            args = (t(s.bg), t(s.means3D), t(s.colors_precomp), t(s.opacities), t(s.scales), t(s.rotations), s.scale_modifier,
+                    t(s.cov3D_precomp), t(s.viewmatrix.reshape(4, 4)), t(s.projmatrix.reshape(4, 4)), s.tanfovx, s.tanfovy, s.H, s.W,
+                    t(s.shs), s.sh_degree, t(s.campos), s.prefiltered, False)
+            for mode in (0, 1):
+                N.lib.gsr_set_backward_moments(mode)
+                R, color, radii, geom, binning, img = N.rasterize_gaussians(*args, need_backward=True)
+                N.rasterize_gaussians_backward(args[0], args[1], radii, args[2], args[4], args[5], s.scale_modifier, args[7], args[8],
+                                               args[9], s.tanfovx, s.tanfovy, t(dL), args[14], s.sh_degree, args[16], geom, R, binning,
+                                               img, False)
+                rec = N.grad_records(geom, s.P).cpu().numpy().astype(np.float64)
+                for n, got in (("mean2D", rec[:, 0:2]), ("conic", rec[:, 2:5])):
+                    m = np.abs(want[n]).max()
+                    if m > 0:
+                        err[mode][n].append(np.abs(got - want[n]).max() / m)
+    finally:
+        N.lib.gsr_set_backward_moments(was)
+    for n in ("mean2D", "conic"):
+        e0, e1 = np.median(err[0][n]), np.median(err[1][n])
+        print("%s: median error of max|g| against the float64 render backward: quadrant-centre moments %.2e, sub-quadrant %.2e" % (n, e0, e1))
+        assert e1 < e0, (n, e0, e1)
