@@ -660,31 +660,6 @@ def main():
                                       "max": max(vals) if vals else None,
                                       "spread": round((max(vals) - min(vals)) / float(np.median(vals)), 4) if vals else None,
                                       "errors": errs or None}
-    depth_hint = None
-    if rank == 0 and not args.no_per_view and not args.no_stage_events and VPC > 1:
-        # ---- side figure (never `value`): the same call shape with DEPTH HINTS on (GSR_DEPTH_HINT=1): the lists of a view are cut where
-        # the previous call on that view stopped consuming them; outputs bit-identical (tests/test_gpu_hints.py), a hint that is
-        # outrun makes the call repeat its binning half.  This workload renders the same 12 views of a static cloud again and again:
-        # the best case for a hint, which is why it is not the headline.
-        try:
-            _native.set_depth_hints(True)
-            st0 = _native.hint_stats()
-            run_steps(warm, 4 * VPC, streams=1, gather_on=False)                  # the first turn only collects hints
-            tsh = [timed(4 * VPC, streams=1) for _ in range(3)]
-            hk, _ = stage_pass(2 * VPC)
-            st1 = _native.hint_stats()
-            _native.set_depth_hints(False)
-            tsp = [timed(4 * VPC, streams=1) for _ in range(3)]                    # the same loop without hints, same streams
-            depth_hint = {"frames_per_s": round(4 * VPC / float(np.median(tsh)), 1),
-                          "frames_per_s_without_hints_same_loop": round(4 * VPC / float(np.median(tsp)), 1),
-                          "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in hk.items()},
-                          "hinted_forwards": st1["hinted_forwards"] - st0["hinted_forwards"], "repeated": st1["repeated"] - st0["repeated"],
-                          "slack": _native.DEPTH_HINT_SLACK,
-                          "note": "opt-in (GSR_DEPTH_HINT=1); one submission in flight; a repeating-view benchmark on a static cloud "
-                                  "is the best case for a hint -- `value` is measured with hints OFF"}
-        except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
-            depth_hint = {"error": repr(ex)}
-            _native.set_depth_hints(False)
     per_rank_blocks = None
     if use_dist:
         cdev = "cpu" if host_collectives else dev
@@ -937,7 +912,7 @@ def main():
                                          if k in bytes_per and v > 0},
             "streams_per_rank": args.streams, "single_stream": single,
             "drop_in_api": drop_in, "per_view_api_frames_per_s": per_view,
-            "forward_only": fwd_only, "rgb_time_equiv": rgb_time, "depth_hint": depth_hint,
+            "forward_only": fwd_only, "rgb_time_equiv": rgb_time,
             "frame_hbm": {"algorithmic_bytes": int(frame_bytes), "gpu_ms_sum": round(frame_gpu_ms, 4),
                           "GBps": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9, 1) if frame_gpu_ms else None,
                           "frac_of_8000": round(frame_bytes / (frame_gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if frame_gpu_ms else None,

@@ -118,7 +118,7 @@ constexpr int MAX_VIEWS = 256;
 // One per (host thread, device): an event belongs to the device that was current when it was created, so a thread that
 // renders on several GPUs needs one landing zone for each.
 struct HostLanding {
-    uint64_t* pinned = nullptr;   // [MAX_VIEWS][LAND_STRIDE]: list pairs, trap flag, stall flag, reference pairs, hint-fail flag (host address)
+    uint64_t* pinned = nullptr;   // [MAX_VIEWS][4]: num_rendered, trap flag, stall flag, -   (host address)
     uint64_t* mapped = nullptr;   // the same memory as the device sees it
     hipEvent_t ev = nullptr;
 };
@@ -129,7 +129,7 @@ static int landing(HostLanding** out)
     if (hipGetDevice(&dev) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] hipGetDevice: %s", hipGetErrorString(hipGetLastError()));
     HostLanding& h = t_lands[dev];
     if (!h.pinned) {
-        if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * LAND_STRIDE * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        if (hipHostMalloc((void**)&h.pinned, MAX_VIEWS * 4 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&h.mapped, h.pinned, 0) != hipSuccess ||
             // (hipEventDisableSystemFence on this event was tried -- the counters live in coherent host memory and the kernel fences
             // them itself, so the record would not need the system-scope release of the L2s -- and cost the per-view path a fifth of
@@ -149,8 +149,6 @@ static thread_local std::vector<int64_t> t_list_pairs;
 
 // device->host read-backs the library has issued since it was loaded (one per forward call: the per-view counters)
 static std::atomic<long long> g_d2h_count{0};
-// hinted forwards since the library was loaded, and how many of them had to repeat their binning half without the filter
-static std::atomic<long long> g_hint_calls{0}, g_hint_repeats{0};
 
 static int tile_count(const gsr_params* p) { return ((p->W + TILE_X - 1) / TILE_X) * ((p->H + TILE_Y - 1) / TILE_Y); }
 
@@ -231,7 +229,7 @@ static int memset_views(hipStream_t s, void* base, size_t stride, size_t bytes, 
 // count-only call; 2 (count only): geometry + pair counting, no binning arena.
 static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
                         size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int mode, hipStream_t stream,
-                        const ExtraChannels* X = nullptr, uint32_t* hint = nullptr, float hint_slack = 0.f)
+                        const ExtraChannels* X = nullptr)
 {
     if (int e = check_params(p, V)) return e;
     if (!num_rendered) return fail(GSR_ERR_INVALID, "[gsr] num_rendered is NULL");
@@ -251,8 +249,6 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     const int T = tile_count(p);
     const int gridx = (p->W + TILE_X - 1) / TILE_X;
     const bool key16 = tile_keys16(T);
-    // depth hints (gsr_forward_batch_hinted): only whole forwards of the default (clipped) lists take them
-    const bool hinted = hint != nullptr && mode == 0 && !p->reference_lists;
 
     if (mode == 1) {
         // the first attempt consumed the frame's bookkeeping: clear it again (k_preprocess did it the first time)
@@ -279,14 +275,14 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     }
     // the emission kernel leaves the counters of every view in mapped host memory; the event behind it is waited for only
     // after the rest of the frame has been enqueued
-    memset(t_land.pinned, 0, (size_t)V * LAND_STRIDE * sizeof(uint64_t));
+    memset(t_land.pinned, 0, (size_t)V * 4 * sizeof(uint64_t));
     // Once the emission is in the stream it WILL store into the landing zone, whatever happens to the launches behind it: an
     // early return must not leave it pending (the next call of this thread clears the zone from the host and would race
     // with those late stores), so every error path below drains the stream first.
-    const auto rest = [&](bool with_hint) -> int {
+    const auto rest = [&]() -> int {
         {
             ProfScope ps("duplicate", L.stream);
-            if (int e = launch_duplicate(L, p->P, B, gridx, key16, t_land.mapped, with_hint)) return e;
+            if (int e = launch_duplicate(L, p->P, B, gridx, key16, t_land.mapped)) return e;
         }
         {
             g_d2h_count++;
@@ -295,75 +291,40 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         }
         if (mode != 2) {
             const int res = sorted_buffer(T);
-            if (with_hint) {
-                ProfScope ps("hint_cut", L.stream);
-                if (int e = launch_hint_cut(L, p->P, B, T, hint)) return e;
-            }
             {
                 ProfScope ps("tile_sort", L.stream);
                 SortJob job{{B.b.key[0], B.b.key[1]}, {B.b.val[0], B.b.val[1]}, B.b.hist, B.b.totals, B.b_stride,
                             B.g.counters + CNT_NUM_RENDERED, B.g_stride, B.b.cap, V};
-                if (with_hint) { job.cut = B.iv.cut; job.cut_stride = B.iv_stride; job.kept = B.g.counters + CNT_NUM_KEPT; }
                 int r2 = 0;
                 if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
             }
             {
                 ProfScope ps("tile_ranges", L.stream);
-                if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16, with_hint)) return e;
+                if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
                 if (int e = launch_tile_order(L, B, T)) return e;
             }
             {
                 ProfScope ps("render_forward", L.stream);
-                if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0, X, hinted)) return e;
-            }
-            if (hinted) {
-                // new hints from what this render consumed; the view's "a cut list was outrun" flag reaches the host with them
-                ProfScope ps("hint_update", L.stream);
-                if (int e = launch_hint_update(L, B, T, B.b.val[res], hint, hint_slack, t_land.mapped)) return e;
-                const hipError_t e = hipEventRecord(t_land.ev, L.stream);   // (re-recorded: the host waits for the END of a hinted forward)
-                if (e != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] hinted forward: %s", hipGetErrorString(e));
+                if (int e = launch_render_forward(L, *p, B, B.b.val[res], out_color, p->need_backward != 0, X)) return e;
             }
         }
         return GSR_OK;
     };
-    if (int e = rest(hinted)) {
+    if (int e = rest()) {
         (void)hipStreamSynchronize(L.stream);   // (keeps g_err: the failure being reported)
         return e;
     }
     if (hipEventSynchronize(t_land.ev) != hipSuccess)
         return fail(GSR_ERR_HIP, "[gsr] num_rendered read-back failed: %s", hipGetErrorString(hipGetLastError()));
-    if (hinted) {
-        // A hint is never trusted: if in some view a tile whose list was cut ended its walk with a live pixel, the binning half of
-        // the frame is repeated WITHOUT the filter (what a resume does: the bookkeeping the first attempt consumed is cleared, the
-        // emission runs again), so every output is the unhinted call's.  The repeat leaves fresh hints behind as well.
-        bool outrun = false, overflow = false;
-        for (int v = 0; v < V; v++) {
-            outrun = outrun || t_land.pinned[LAND_STRIDE * v + LAND_HINT_FAIL] != 0;
-            overflow = overflow || (int64_t)t_land.pinned[LAND_STRIDE * v + CNT_NUM_RENDERED] > B.b.cap;
-        }
-        g_hint_calls++;
-        if (outrun && !overflow) {
-            g_hint_repeats++;
-            if (int e = memset_views(L.stream, B.g.zero_begin, B.g_stride, B.g.zero_bytes, V)) return e;
-            if (int e = memset_views(L.stream, B.iv.zero_begin, B.iv_stride, B.iv.zero_bytes, V)) return e;
-            memset(t_land.pinned, 0, (size_t)V * LAND_STRIDE * sizeof(uint64_t));
-            if (int e = rest(false)) {
-                (void)hipStreamSynchronize(L.stream);
-                return e;
-            }
-            if (hipEventSynchronize(t_land.ev) != hipSuccess)
-                return fail(GSR_ERR_HIP, "[gsr] hinted forward (repeat): %s", hipGetErrorString(hipGetLastError()));
-        }
-    }
     bool retry = false;
     t_list_pairs.assign((size_t)V, 0);
     for (int v = 0; v < V; v++) {
         // R: pairs of the reference's tile rectangles (what the reference calls num_rendered); L: pairs in this library's
         // lists (fewer when the rectangles are clipped to the splats' footprints) -- the arena has to hold L
-        const uint64_t R = t_land.pinned[LAND_STRIDE * v + LAND_NUM_REFERENCE], Lp = t_land.pinned[LAND_STRIDE * v + CNT_NUM_RENDERED];
-        if (t_land.pinned[LAND_STRIDE * v + CNT_STALL])
+        const uint64_t R = t_land.pinned[4 * v + LAND_NUM_REFERENCE], Lp = t_land.pinned[4 * v + CNT_NUM_RENDERED];
+        if (t_land.pinned[4 * v + CNT_STALL])
             return fail(GSR_ERR_HIP, "[gsr] pair emission: a workgroup's pair count never arrived (view %d)", v);
-        if (p->prefiltered && t_land.pinned[LAND_STRIDE * v + CNT_TRAP])
+        if (p->prefiltered && t_land.pinned[4 * v + CNT_TRAP])
             return fail(GSR_ERR_TRAP, "Point is filtered although prefiltered is set. This shouldn't happen!");
         // the reference keeps num_rendered in an int (CR/rasterizer_impl.cu:280); beyond that its arena sizes wrap
         if (R > 0x7FFFFFFFull)
@@ -409,21 +370,6 @@ int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t ge
     const ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra, extra_per_view ? (size_t)p->P * (size_t)nx : (size_t)0};
     return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
                         resume ? 1 : 0, (hipStream_t)stream, &X);
-}
-
-int gsr_forward_batch_hinted(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes, void* binning,
-                             size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume,
-                             uint32_t* depth_hint, float slack, gsr_stream_t stream)
-{
-    if (depth_hint != nullptr && !(slack >= 0.f && slack <= 4.f)) return fail(GSR_ERR_INVALID, "[gsr] depth-hint slack outside 0..4");
-    return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
-                        resume ? 1 : 0, (hipStream_t)stream, nullptr, depth_hint, slack);
-}
-
-void gsr_hint_stats(long long* calls, long long* repeats)
-{
-    if (calls) *calls = gsr::g_hint_calls.load();
-    if (repeats) *repeats = gsr::g_hint_repeats.load();
 }
 
 int gsr_forward_stage1(const gsr_params* p, void* geom, size_t geom_bytes, void* image, size_t image_bytes, int* radii,

@@ -70,8 +70,7 @@ struct DupArgs {
     uint32_t* vals;
     size_t b_stride;
     int64_t cap;
-    uint64_t* host_land;             // [V][LAND_STRIDE] host memory mapped into the device: num_rendered, trap flag, stall flag, ... (api.hip)
-    uint32_t* pair_off;              // hinted calls (else NULL): [P] first emission position of the Gaussian at each depth rank
+    uint64_t* host_land;             // [V][4] host memory mapped into the device: num_rendered, trap flag, stall flag, - (api.hip)
 };
 
 template <typename KeyT>
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
                 v[k] = agent_load(&status[b0 + k * DUP_THREADS]);
                 if ((uint32_t)v[k] == 0u && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
                     at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
-                    a.host_land[LAND_STRIDE * view + CNT_STALL] = 1;
+                    a.host_land[4 * view + CNT_STALL] = 1;
                     v[k] = 1;
                 }
             }
@@ -220,9 +219,9 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
             const uint64_t ref_total = s_ref[0] + s_ref[1] + s_ref[2] + s_ref[3] + block_ref;
             cnt[CNT_NUM_RENDERED] = base + block_total;
             cnt[CNT_NUM_REFERENCE] = ref_total;
-            a.host_land[LAND_STRIDE * view + CNT_NUM_RENDERED] = base + block_total;
-            a.host_land[LAND_STRIDE * view + CNT_TRAP] = cnt[CNT_TRAP];
-            a.host_land[LAND_STRIDE * view + LAND_NUM_REFERENCE] = ref_total;
+            a.host_land[4 * view + CNT_NUM_RENDERED] = base + block_total;
+            a.host_land[4 * view + CNT_TRAP] = cnt[CNT_TRAP];
+            a.host_land[4 * view + LAND_NUM_REFERENCE] = ref_total;
             __threadfence_system();
         }
     }
@@ -233,17 +232,6 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     KeyT* keys = at_view((KeyT*)a.keys, a.b_stride, view);
     uint32_t* vals = at_view(a.vals, a.b_stride, view);
     const uint64_t wave_off = s_base + wave_base;
-    if (a.pair_off != nullptr) {
-        // hinted call: where each depth rank's pairs begin in the emission array (positions beyond 2^32 - 2 saturate: such a frame
-        // does not fit any arena and is retried)
-        uint32_t* po = at_view(a.pair_off, a.g_stride, view);
-#pragma unroll
-        for (int g = 0; g < DUP_G; g++) {
-            const int slot = slot0 + g * 64;
-            const uint64_t o = wave_off + excl[g];
-            if (slot < a.P) po[slot] = o < 0xFFFFFFFEull ? (uint32_t)o : 0xFFFFFFFEu;
-        }
-    }
 
 #pragma unroll 1
     for (int g = 0; g < DUP_G; g++) {
@@ -331,7 +319,7 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
 #endif
 }
 
-int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land, bool store_pair_off)
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land)
 {
     DupArgs a;
     a.P = P;
@@ -348,7 +336,6 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     a.b_stride = B.b_stride;
     a.cap = B.b.key[0] ? B.b.cap : 0;
     a.host_land = host_land;
-    a.pair_off = store_pair_off ? B.g.pair_off : nullptr;
     const dim3 grid((unsigned)div_up(P, DUP_BLOCK), B.V);
     if (key16)
         hipLaunchKernelGGL(k_duplicate<uint16_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);
@@ -394,12 +381,12 @@ constexpr int RANGE_TILES_PER_WG = 255;
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict__ counters, size_t g_stride, int64_t cap,
                                                      const KeyT* __restrict__ keys, size_t b_stride, uint2* __restrict__ ranges,
-                                                     size_t iv_stride, int T, int count_slot)
+                                                     size_t iv_stride, int T)
 {
     __shared__ uint32_t samples[RANGE_MAX_SAMPLES];
     __shared__ uint32_t bound[256];
     const uint32_t view = blockIdx.y;
-    const uint64_t n64 = at_view(counters, g_stride, view)[count_slot];   // pairs in the sorted lists (hinted calls: the ones kept)
+    const uint64_t n64 = at_view(counters, g_stride, view)[CNT_NUM_RENDERED];
     const uint32_t n = (uint32_t)(n64 < (uint64_t)cap ? n64 : (uint64_t)cap);
     keys = at_view(keys, b_stride, view);
     ranges = at_view(ranges, iv_stride, view);
@@ -415,96 +402,16 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict_
     ranges[t] = first < last ? make_uint2(first, last) : make_uint2(0u, 0u);
 }
 
-int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16, bool kept_count)
+int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16)
 {
     const dim3 grid((unsigned)div_up(T, RANGE_TILES_PER_WG), B.V);
-    const int slot = kept_count ? CNT_NUM_KEPT : CNT_NUM_RENDERED;
     if (key16)
         hipLaunchKernelGGL(k_tile_ranges<uint16_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap,
-                           (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride, T, slot);
+                           (const uint16_t*)sorted_keys, B.b_stride, B.iv.ranges, B.iv_stride, T);
     else
         hipLaunchKernelGGL(k_tile_ranges<uint32_t>, grid, dim3(256), 0, L.stream, B.g.counters, B.g_stride, B.b.cap, sorted_keys,
-                           B.b_stride, B.iv.ranges, B.iv_stride, T, slot);
+                           B.b_stride, B.iv.ranges, B.iv_stride, T);
     return check_launch(L, "tile_ranges");
-}
-
-// ---- depth hints -----------------------------------------------------------------------------------------------------------
-// 84 % of the sorted pairs of a dense cloud are never read: the forward render stops where the pixels saturate.  A caller that
-// renders the same views again and again (a training loop over a fixed set of cameras) can hand the library a HINT per (view,
-// tile): the depth up to which the tile's list was consumed the last time, with some slack.  Pairs of Gaussians deeper than a
-// tile's hint are left out by the first pass of the tile sort.  A hint is never trusted: a tile whose list was cut and whose walk
-// ends with a live pixel makes the whole call repeat its binning half without the filter (api.hip), so every output is what the
-// unhinted call produces, bit for bit.
-// The emission writes pairs in depth order, so "deeper than the hint" is "at or behind a position of the emission array":
-// cut[t] = pair_off[r], r = number of Gaussians whose depth key is <= hint[t] (binary search of the depth-sorted keys).
-__global__ __launch_bounds__(256) void k_hint_cut(int P, int T, const uint32_t* __restrict__ hint, const uint32_t* __restrict__ dkey0,
-                                                  const uint32_t* __restrict__ dkey1, const uint32_t* __restrict__ sortctl,
-                                                  const uint32_t* __restrict__ pair_off, uint64_t* __restrict__ counters, size_t g_stride,
-                                                  uint32_t* __restrict__ cut, size_t iv_stride)
-{
-    const uint32_t view = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) {
-        uint64_t* c = at_view(counters, g_stride, view);
-        c[CNT_NUM_KEPT] = 0;
-        c[CNT_HINT_FAIL] = 0;
-    }
-    if (t >= T) return;
-    const uint32_t h = hint[(size_t)view * T + t];
-    uint32_t c = HINT_KEEP_ALL;
-    if (h != HINT_KEEP_ALL) {
-        const uint32_t npass = depth_sort_passes(at_view(sortctl, g_stride, view)[SORTCTL_BITS]);
-        const uint32_t* keys = at_view((npass & 1u) ? dkey1 : dkey0, g_stride, view);   // the depth keys in sorted order
-        uint32_t lo = 0, hi = (uint32_t)P;                                            // first rank whose key is > h
-        while (lo < hi) {
-            const uint32_t m = (lo + hi) >> 1;
-            if (keys[m] <= h) lo = m + 1; else hi = m;
-        }
-        if (lo < (uint32_t)P) c = at_view(pair_off, g_stride, view)[lo];
-    }
-    at_view(cut, iv_stride, view)[t] = c;
-}
-
-int launch_hint_cut(const Launch& L, int P, const Batch& B, int T, const uint32_t* hint)
-{
-    hipLaunchKernelGGL(k_hint_cut, dim3((unsigned)div_up(T, 256), B.V), dim3(256), 0, L.stream, P, T, hint, B.g.dkey[0], B.g.dkey[1],
-                       B.g.sortctl, B.g.pair_off, B.g.counters, B.g_stride, B.iv.cut, B.iv_stride);
-    return check_launch(L, "hint_cut");
-}
-
-// After the render: a tile all of whose pixels terminated (no quadrant wave ended with a live pixel) gets the depth of the LAST entry
-// it consumed -- the one that stopped its last pixel -- times (1 + slack) as its next hint; every other tile keeps everything.
-// Thread 0 of a view also hands the host the view's "a cut list was outrun" flag.
-__global__ __launch_bounds__(256) void k_hint_update(int T, const uint32_t* __restrict__ need, const uint32_t* __restrict__ live,
-                                                     const uint2* __restrict__ ranges, size_t iv_stride,
-                                                     const uint32_t* __restrict__ point_list, size_t b_stride,
-                                                     const Splat* __restrict__ splat, const uint64_t* __restrict__ counters, size_t g_stride,
-                                                     uint32_t* __restrict__ hint, float slack, uint64_t* __restrict__ host_land)
-{
-    const uint32_t view = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) {
-        host_land[LAND_STRIDE * view + LAND_HINT_FAIL] = at_view(counters, g_stride, view)[CNT_HINT_FAIL];
-        __threadfence_system();
-    }
-    if (t >= T) return;
-    const uint32_t n = at_view(need, iv_stride, view)[t];
-    uint32_t h = HINT_KEEP_ALL;
-    if (n != 0 && at_view(live, iv_stride, view)[t] == 0) {
-        const uint2 r = at_view(ranges, iv_stride, view)[t];
-        const uint32_t id = at_view(point_list, b_stride, view)[r.x + n - 1];
-        const float d = at_view(splat, g_stride, view)[id].q2.y * (1.f + slack);   // view-space depth > 0.2: the float's bits order like it
-        h = __float_as_uint(d);
-        if (!(d > 0.f) || h >= HINT_KEEP_ALL - 1u) h = HINT_KEEP_ALL;
-    }
-    hint[(size_t)view * T + t] = h;
-}
-
-int launch_hint_update(const Launch& L, const Batch& B, int T, const uint32_t* point_list, uint32_t* hint, float slack, uint64_t* host_land)
-{
-    hipLaunchKernelGGL(k_hint_update, dim3((unsigned)div_up(T, 256), B.V), dim3(256), 0, L.stream, T, B.iv.tile_need, B.iv.tile_live,
-                       B.iv.ranges, B.iv_stride, point_list, B.b_stride, B.g.splat, B.g.counters, B.g_stride, hint, slack, host_land);
-    return check_launch(L, "hint_update");
 }
 
 // ---- render launch order: tiles by descending work estimate (128 quarter-octave buckets) -------------

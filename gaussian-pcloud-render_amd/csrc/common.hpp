@@ -90,13 +90,6 @@ constexpr int CNT_NUM_REFERENCE = 4; // pairs of the reference's unclipped tile 
 constexpr int LAND_NUM_REFERENCE = 3; // its slot in the host landing zone ([V][4]: CNT_NUM_RENDERED, CNT_TRAP, CNT_STALL, this)
 constexpr int CNT_BWD_DIRTY = 3;     // a backward has accumulated into this view's gradient records since the forward cleared
                                      // them: the next backward on the same arenas clears them first (k_bwd_items)
-// depth hints (gsr_forward_batch_hinted; binning.hip k_hint_cut): pairs that survived the first tile-sort pass' filter; and "a tile
-// whose list was cut ended its walk with live pixels" (the frame is then repeated without the filter)
-constexpr int CNT_NUM_KEPT = 5;
-constexpr int CNT_HINT_FAIL = 6;
-constexpr int LAND_STRIDE = 8;       // words per view in the host landing zone
-constexpr int LAND_HINT_FAIL = 4;    // its slot there
-constexpr uint32_t HINT_KEEP_ALL = 0xFFFFFFFFu;   // hint / cut value of a tile whose list is not to be cut
 
 // ---- arena views (device pointers carved out of the caller's opaque buffers) -------------------
 struct GeomView {
@@ -109,8 +102,6 @@ struct GeomView {
     uint32_t* totals;         // [RADIX]
     uint32_t* blk_minmax;     // [2 * nblk(P)] smallest / largest depth key of a visible Gaussian per sort block (pass 0's histogram)
     uint32_t* sortctl;        // [4] SORTCTL_*: which key bits the depth sort really has to look at this frame (sort.hip)
-    uint32_t* pair_off;       // [P] first pair (position in the emission array) of the Gaussian at each depth rank; written by the
-                              // emission for hinted calls only (a tile's depth hint becomes a position in that array: k_hint_cut)
     uint64_t* dup_status;     // [ceil(P / DUP_THREADS) + 1] pair count + 1 of each emission workgroup, then the ticket counter
     uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
     char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
@@ -150,8 +141,6 @@ struct BinView {
 struct ImageView {
     uint32_t* tile_need;  // [T] entries walked by the forward render  } cleared by k_preprocess at the start of
     uint32_t* bwd_count;  // [4] number of backward items              } every frame
-    uint32_t* tile_live;  // [T] quadrant waves of the tile whose walk ended with live pixels (hinted calls)  } likewise
-    uint32_t* cut;        // [T] hinted calls: pairs of the tile at emission positions >= cut are left out of the lists (HINT_KEEP_ALL: none)
     uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
@@ -188,7 +177,6 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.totals, (size_t)RADIX);
     carve(cur, g.blk_minmax, 2 * nblk);
     carve(cur, g.sortctl, (size_t)4);
-    carve(cur, g.pair_off, p);
     g.zero_begin = cur;
     carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS) + 1);   // + the ticket counter
     g.zero_bytes = (size_t)(cur - g.zero_begin);
@@ -236,9 +224,7 @@ inline ImageView image_view(void* base, int W, int H)
     v.zero_begin = cur;
     carve(cur, v.tile_need, T ? T : 1);
     carve(cur, v.bwd_count, (size_t)4);
-    carve(cur, v.tile_live, T ? T : 1);
     v.zero_bytes = (size_t)(cur - v.zero_begin);
-    carve(cur, v.cut, T ? T : 1);
     carve(cur, v.ranges, T ? T : 1);
     carve(cur, v.final_T, N ? N : 1);
     carve(cur, v.n_contrib, N ? N : 1);
@@ -307,12 +293,6 @@ struct SortJob {
     uint32_t* blk_minmax = nullptr;   // [2 * nblk_pad] per view
     uint32_t* sortctl = nullptr;      // [4] per view
     bool small_blocks = false;        // u32 keys, 8-bit digits only: blocks of RS_TILE_SMALL keys (hist / blk_minmax carved for them)
-    // Tile sort of a hinted call (else NULL): pass 0 leaves out the pairs at positions >= cut[key] (per view, stride cut_stride),
-    // adds the number of pairs it kept to *kept (per view, stride n_stride; zeroed by the caller) and the later passes, like
-    // everything behind the sort, work on that many elements
-    const uint32_t* cut = nullptr;
-    size_t cut_stride = 0;
-    uint64_t* kept = nullptr;
 };
 // sortctl words: keys are compared as (key - SORTCTL_BASE) on bits [0, SORTCTL_BITS); SORTCTL_BASE has its low 8 bits clear, so
 // pass 0 (which runs before the words exist) sees the same digit either way
@@ -324,12 +304,8 @@ __host__ __device__ inline uint32_t depth_sort_passes(uint32_t bits) { return (b
 int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16 = false);
 inline bool tile_keys16(int T) { return T <= 65536; }
 // binning.hip
-int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land, bool store_pair_off = false);
-int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16, bool kept_count = false);
-// depth hints: hint [V][T] (u32 depth-key thresholds, HINT_KEEP_ALL = no cut) -> cut[T] per view (+ clears the hinted call's counters);
-// after the render: hint <- depth of the last entry the tile consumed x (1 + slack) for tiles whose pixels all terminated
-int launch_hint_cut(const Launch& L, int P, const Batch& B, int T, const uint32_t* hint);
-int launch_hint_update(const Launch& L, const Batch& B, int T, const uint32_t* point_list, uint32_t* hint, float slack, uint64_t* host_land);
+int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land);
+int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16);
 int launch_tile_order(const Launch& L, const Batch& B, int T);
 int launch_bwd_items(const Launch& L, const Batch& B, int T, int P);
 // render_fwd.hip / render_bwd.hip
@@ -344,7 +320,7 @@ struct ExtraChannels {
     size_t view_stride;       // floats between consecutive views' value arrays (0: one array shared by the views)
 };
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
-                          bool with_ckpt, const ExtraChannels* X = nullptr, bool hinted = false);
+                          bool with_ckpt, const ExtraChannels* X = nullptr);
 int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, const float* dL_dpix);
 int backward_subquadrant_moments(int set);   // render_bwd.hip: set >= 0 stores; 1 = moments about the sub-quadrant centres
 int forward_half_views(int set);   // render_fwd.hip: set >= 0 stores; returns the views per submission up to which the half-quadrant forward runs

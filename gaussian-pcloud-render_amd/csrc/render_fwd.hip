@@ -56,19 +56,7 @@ struct RenderArgs {
     const float* extra_scale;  // [V][NX] per-view factors applied to them (NULL: 1), e.g. the +-1 of view-dependent normals
     const float* bg_extra;     // [NX]
     float* out_extra;          // [V][NX][H][W]
-    // hinted calls (binning.hip k_hint_cut), else NULL: a wave whose walk ends with a live pixel counts itself in tile_live[tile]
-    // (the tile did not saturate: its next hint keeps everything) and, if the tile's list was cut, raises the view's CNT_HINT_FAIL
-    const uint32_t* cut;
-    uint32_t* tile_live;
-    uint64_t* counters;
 };
-
-__device__ __forceinline__ void note_live_tile(const RenderArgs& a, uint32_t view, uint32_t tile, uint32_t lane)
-{
-    if (lane != 0) return;
-    atomicAdd(&at_view(a.tile_live, a.iv_stride, view)[tile], 1u);
-    if (at_view(a.cut, a.iv_stride, view)[tile] != HINT_KEEP_ALL) at_view(a.counters, a.g_stride, view)[CNT_HINT_FAIL] = 1;
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -512,7 +500,6 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
 #endif
     // instrumentation: how many list entries this tile really needed (max over its pixels); tile_need is zeroed
     // before the launch
-    if (a.tile_live != nullptr && !__all(done)) note_live_tile(a, view, tile, lane);   // (uniform) some pixel is still live at the end of the list
     {
         uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
 #pragma unroll
@@ -780,7 +767,6 @@ __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
             id_nxt = id_nn;
         }
     }
-    if (a.tile_live != nullptr && !__all(done)) note_live_tile(a, view, tile, lane);   // (uniform) some pixel is still live at the end of the list
     {
         uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
 #pragma unroll
@@ -822,7 +808,7 @@ int forward_half_views(int set)
 }
 
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
-                          bool with_ckpt, const ExtraChannels* X, bool hinted)
+                          bool with_ckpt, const ExtraChannels* X)
 {
     RenderArgs a;
     a.ranges = B.iv.ranges;
@@ -846,9 +832,6 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     a.chunk_shift = B.chunk_shift();
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
     a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr; a.extra_vstride = 0;
-    a.cut = hinted ? B.iv.cut : nullptr;
-    a.tile_live = hinted ? B.iv.tile_live : nullptr;
-    a.counters = B.g.counters;
     const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);
     if (X != nullptr && X->nx > 0) {
         a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out; a.extra_vstride = X->view_stride;

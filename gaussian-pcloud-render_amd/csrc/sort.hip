@@ -55,8 +55,6 @@ struct SortView {
     size_t n_stride;
     int64_t cap;
     const uint32_t* ctl;   // sortctl of view 0 (depth sort, passes 1..3) or NULL
-    const uint32_t* cut;   // pass 0 of a hinted tile sort (else NULL): the pair at position i with key k is kept iff i < cut[k]
-    size_t cut_stride;
 };
 // The depth sort's later passes compare (key - base) and leave at once when their bits are above every difference between two
 // keys of visible Gaussians (wave-uniform: one scalar load).  Returns false when the pass has nothing to do.
@@ -112,18 +110,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     const uint32_t w = (threadIdx.x >> 6) * 4u + (threadIdx.x & 3u);
-    const uint32_t* cut = sv.cut ? at_view(sv.cut, sv.cut_stride, view) : nullptr;
-    if (cut != nullptr) {
-        // hinted tile sort, pass 0: only the pairs in front of their tile's cut are counted (k_radix_scatter leaves the others out)
-#pragma unroll
-        for (int i = 0; i < RS_ITEMS; i++) {
-            const int64_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) {
-                const uint32_t key = (uint32_t)keys[idx];
-                if ((uint32_t)idx < cut[key]) atomicAdd(&h[w][(key >> shift) & mask], 1u);
-            }
-        }
-    } else if (sizeof(KeyT) == 2 && RS_ITEMS % 8 == 0 && base + RS_TILE <= n) {
+    if (sizeof(KeyT) == 2 && RS_ITEMS % 8 == 0 && base + RS_TILE <= n) {
         // full block of 16-bit keys: 16-B loads of eight keys instead of 2-B ones (counting is order-free)
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base) + threadIdx.x * (RS_ITEMS / 8);
 #pragma unroll
@@ -174,7 +161,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const KeyT* __restric
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblk_pad,
                                                        size_t stride, const uint32_t* __restrict__ ctl, int shift,
                                                        const uint32_t* __restrict__ minmax, uint32_t* __restrict__ ctl_out,
-                                                       uint32_t nrows, uint64_t* __restrict__ kept, size_t kept_stride)
+                                                       uint32_t nrows)
 {
     __shared__ uint32_t tmp[4];
     if (blockIdx.x == nrows) {
@@ -214,11 +201,7 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
         if (b < nblk_pad) row[b] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) {
-        totals[blockIdx.x] = carry;
-        // hinted tile sort, pass 0: the digit rows' totals add up to the number of pairs the filter kept
-        if (kept != nullptr && carry != 0) atomicAdd((unsigned long long*)at_view(kept, kept_stride, blockIdx.y), (unsigned long long)carry);
-    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 #ifdef GSR_STATS
@@ -282,7 +265,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     __shared__ uint32_t tmp[4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint32_t kept_here = 0;                      // elements of this block that take part (all of them without a cut)
     const int64_t blk_base = (int64_t)blk * RS_TILE;
     const int64_t seg_base = blk_base + (int64_t)w * (RS_TILE / RS_WAVES);
 
@@ -294,9 +276,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     const uint32_t hist_d = tid <= mask ? hist[(size_t)tid * nblk_pad + blk] : 0u;
 
     uint32_t k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
-    const uint32_t* cut = sv.cut ? at_view(sv.cut, sv.cut_stride, view) : nullptr;
-    const bool full = cut == nullptr && blk_base + RS_TILE <= n;   // all but the last block of a view: no bounds checks
-    uint32_t okbits = 0;                         // (not full) bit j: element j of this thread takes part
+    const bool full = blk_base + RS_TILE <= n;   // all but the last block of a view: no bounds checks
     {
         const KeyT* kp = keys_in + seg_base + lane;
         const uint32_t* vp = vals_in ? vals_in + seg_base + lane : nullptr;
@@ -315,12 +295,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
 #pragma unroll
             for (int j = 0; j < RS_ITEMS; j++) {
                 const int64_t idx = seg_base + j * 64 + lane;
-                bool ok = idx < n;
-                uint32_t key = ok ? (uint32_t)kp[j * 64] : 0u;
-                if (cut != nullptr && ok) ok = (uint32_t)idx < cut[key];   // hinted tile sort, pass 0 (kbase = 0 there)
-                k[j] = ok ? key - kbase : 0xFFFFFFFFu;
+                const bool ok = idx < n;
+                k[j] = ok ? (uint32_t)kp[j * 64] - kbase : 0xFFFFFFFFu;
                 v[j] = ok ? (vp ? vp[j * 64] : (uint32_t)idx) : 0u;
-                okbits |= (ok ? 1u : 0u) << j;
             }
         }
     }
@@ -340,7 +317,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     // comes from mbcnt.  This loop is most of the kernel's instructions -- the scatter is VALU-bound, not HBM-bound.
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
-        const bool ok = full || ((okbits >> j) & 1u) != 0;
+        const bool ok = full || seg_base + j * 64 + lane < n;
         const uint32_t d = (k[j] >> shift) & mask;
         const uint64_t okb = full ? ~0ull : __ballot(ok);
         uint32_t plo = (uint32_t)okb, phi = (uint32_t)(okb >> 32);
@@ -372,7 +349,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             wave_cnt[i][d] = run;
             run += c[i];
         }
-        const uint32_t lb = block_exclusive_scan_256(run, tmp, &kept_here);
+        const uint32_t lb = block_exclusive_scan_256(run, tmp, nullptr);
         local_base[d] = lb;
         global_base[d] = gbase_d;
     }
@@ -382,7 +359,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
 
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
-        if (full || ((okbits >> j) & 1u) != 0) {
+        if (full || seg_base + j * 64 + lane < n) {
             const uint32_t d = (k[j] >> shift) & mask;
             const uint32_t pos = local_base[d] + wave_cnt[w][d] + rank[j];
             s_key[pos] = k[j];
@@ -393,7 +370,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     SC_T(t4);
     SC_PUT(3, t4 - t3);
 
-    const uint32_t count = kept_here;
+    const int64_t rem = n - blk_base;
+    const uint32_t count = rem < RS_TILE ? (uint32_t)rem : (uint32_t)RS_TILE;
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const uint32_t p = i * RS_THREADS + tid;
@@ -420,7 +398,7 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
         const int tile = small ? RS_TILE_SMALL : RS_TILE;
         const int nblk = (int)div_up(job.cap, tile);
         const int nblk_pad = sort_hist_stride(job.cap, tile);
-        SortView sv{job.stride, job.n_dev, job.n_stride, job.cap, nullptr, nullptr, 0};
+        SortView sv{job.stride, job.n_dev, job.n_stride, job.cap, nullptr};
         const dim3 grid_hist(nblk_pad, job.V);
         const dim3 grid((unsigned)div_up(nblk, 8 * HIST_GROUP) * 8 * HIST_GROUP, job.V);   // see the workgroup -> block map
         bool first = true;
@@ -432,10 +410,6 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
             // depth sort: pass 0 produces the control words, the later passes obey them
             const bool make_ctl = job.sortctl != nullptr && pass == 0;
             sv.ctl = (job.sortctl != nullptr && pass > 0) ? job.sortctl : nullptr;
-            // hinted tile sort: pass 0 filters all the pairs, the later passes see the ones it kept
-            sv.cut = (job.cut != nullptr && pass == 0) ? job.cut : nullptr;
-            sv.cut_stride = job.cut_stride;
-            if (job.cut != nullptr && pass > 0) sv.n_dev = job.kept;
             uint32_t* minmax = make_ctl ? job.blk_minmax : nullptr;
             if (key16)
                 hipLaunchKernelGGL((k_radix_hist<uint16_t, RS_ITEMS>), grid_hist, dim3(RS_THREADS), 0, L.stream, (const uint16_t*)job.key[cur], sv,
@@ -448,8 +422,7 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
                                    shift, mask, job.hist, nblk_pad, minmax);
             if (int e = check_launch(L, "radix_hist")) return e;
             hipLaunchKernelGGL(k_radix_rowscan, dim3(mask + 1u + (make_ctl ? 1u : 0u), job.V), dim3(256), 0, L.stream, job.hist,
-                               job.totals, nblk_pad, job.stride, sv.ctl, shift, (const uint32_t*)minmax, job.sortctl, mask + 1u,
-                               (job.cut != nullptr && pass == 0) ? job.kept : (uint64_t*)nullptr, job.n_stride);
+                               job.totals, nblk_pad, job.stride, sv.ctl, shift, (const uint32_t*)minmax, job.sortctl, mask + 1u);
             if (int e = check_launch(L, "radix_rowscan")) return e;
             const uint32_t* vin = (first && iota_vals) ? (const uint32_t*)nullptr : (const uint32_t*)job.val[cur];
 #define GSR_SCATTER(B)                                                                                                        \

@@ -35,7 +35,7 @@ SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
            "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
            "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs", "gsr_set_forward_half_views",
-           "gsr_set_backward_moments", "gsr_forward_batch_hinted", "gsr_hint_stats")
+           "gsr_set_backward_moments")
 
 GSR_RETRY = 1
 
@@ -60,11 +60,6 @@ def _load():
     lib.gsr_forward_batch.restype = C.c_int
     lib.gsr_forward_batch.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
                                       C.POINTER(C.c_int64), C.c_int, _fp]
-    lib.gsr_forward_batch_hinted.restype = C.c_int
-    lib.gsr_forward_batch_hinted.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t, _fp, _fp,
-                                             C.POINTER(C.c_int64), C.c_int, _fp, C.c_float, _fp]
-    lib.gsr_hint_stats.restype = None
-    lib.gsr_hint_stats.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.gsr_forward_batch_channels.restype = C.c_int
     lib.gsr_forward_batch_channels.argtypes = [C.POINTER(GsrParams), C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp, C.c_size_t,
                                                _fp, _fp, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]
@@ -357,17 +352,13 @@ class _OnSideStream:
 
 def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                              camposs, prefiltered, debug, need_backward=True, capacity=None, extra=None, depth_hint=None,
-                              hint_slack=None):
+                              camposs, prefiltered, debug, need_backward=True, capacity=None, extra=None):
     """V views of one cloud in one submission (C ABI gsr_forward_batch): viewmatrices / projmatrices [V,4,4] (transposed like
     the reference's settings), camposs [V,3].  Returns (num_rendered list[V], out_color [V,3,H,W], radii [V,P],
     geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity.
     extra = (values [P,nx] shared by the views or [V,P,nx] per view, view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the
     render also composites those channels with the colour's alphas (gsr_forward_batch_channels) and the result gains a 7th
-    element, out_extra [V,nx,H,W].
-    depth_hint: an int32 device tensor [V, T] from new_depth_hints() that the caller keeps for THESE views (C ABI
-    gsr_forward_batch_hinted: the lists are cut where the previous call with the same buffer stopped consuming them; outputs are the
-    unhinted call's bit for bit -- a hint that turns out too tight makes the call repeat its binning half -- and the buffer is updated)."""
+    element, out_extra [V,nx,H,W]."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = means3D.device
@@ -392,24 +383,6 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         r0 = ([0] * V, torch.zeros((V, 3, H, W), dtype=torch.float32, device=device),
               torch.zeros((V, 0), dtype=torch.int32, device=device), e, e.clone(), e.clone())
         return r0 if extra is None else r0 + (torch.zeros((V, nx, H, W), dtype=torch.float32, device=device),)
-    if depth_hint is None and _DEPTH_HINTS_ON and not nx and P != 0 and not reference_lists():
-        # opt-in (GSR_DEPTH_HINT=1): one hint buffer per set of views, identified by the view matrices' tensor (address, shape,
-        # version): a caller that keeps its settings tensors (or a rasterize_views settings list, whose packed block is cached) gets
-        # its lists cut where the previous call on these views stopped consuming them; anything else just renders unhinted or, at
-        # worst, repeats its binning half -- the outputs are the same either way
-        try:
-            vkey = (viewmatrices.data_ptr(), tuple(viewmatrices.shape), viewmatrices._version, int(P))
-        except RuntimeError:
-            vkey = None
-        if vkey is not None:
-            depth_hint = depth_hints_for(vkey, V, W, H, device)
-    if depth_hint is not None:
-        T_ = ((W + 15) // 16) * ((H + 15) // 16)
-        if nx or depth_hint.dtype != torch.int32 or tuple(depth_hint.shape) != (V, T_) or depth_hint.device != device or \
-                not depth_hint.is_contiguous():
-            raise RuntimeError("depth_hint: an int32 tensor of shape (views, tiles) on the cloud's device (new_depth_hints), "
-                               "not combined with extra channels")
-        hint_slack = DEPTH_HINT_SLACK if hint_slack is None else hint_slack
     key = _cap_key(device, P, W, H)
     # everything below -- layout conversions of the inputs, the allocation of outputs and arenas, every kernel -- happens on a side
     # stream that waits for the inputs only (see _OnSideStream); the caller's stream takes the results over when the block ends
@@ -440,7 +413,7 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
         if capacity is None:
             hint = _CAP_HINT.get(key)
             capacity = None if hint is None else int(hint * CAP_SLACK) + 4096
-        if capacity is None and V == 1 and not nx and depth_hint is None:
+        if capacity is None and V == 1 and not nx:
             # first frame of this configuration: count, then bind (one host round trip, like the reference)
             _check(lib.gsr_forward_stage1(C.byref(p), geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
                                           radii.data_ptr(), counts, stream))
@@ -456,10 +429,6 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
                         C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(), binning.data_ptr(),
                         binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts, resume, nx, x_per_view, xv.data_ptr(),
                         None if xs is None else xs.data_ptr(), xb.data_ptr(), out_extra.data_ptr(), stream)
-                if depth_hint is not None:
-                    return lib.gsr_forward_batch_hinted(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
-                                                        binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(),
-                                                        counts, resume, depth_hint.data_ptr(), float(hint_slack), stream)
                 return lib.gsr_forward_batch(C.byref(p), V, geom.data_ptr(), geom.numel(), img.data_ptr(), img.numel(),
                                              binning.data_ptr(), binning.numel(), radii.data_ptr(), out_color.data_ptr(), counts,
                                              resume, stream)
@@ -482,46 +451,6 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     if nx:
         return counts, out_color, radii, geom, binning, img, out_extra
     return counts, out_color, radii, geom, binning, img
-
-
-# ---- depth hints (opt-in: GSR_DEPTH_HINT=1 / set_depth_hints(True)) -------------------------------------------------------------------
-# A caller that renders the SAME views again and again gets shorter sorts: the library keeps one hint buffer per set of views (keyed by
-# the settings tensors' identity, like the view-block cache) and hands it to gsr_forward_batch_hinted.  Outputs are unchanged bit for
-# bit; a view seen for the first time, or fresh settings tensors on every call, simply render unhinted.
-DEPTH_HINT_SLACK = float(os.environ.get("GSR_DEPTH_HINT_SLACK", "0.02"))
-_DEPTH_HINTS_ON = os.environ.get("GSR_DEPTH_HINT", "0") == "1"
-_DEPTH_HINTS = {}
-
-
-def set_depth_hints(on):
-    global _DEPTH_HINTS_ON
-    _DEPTH_HINTS_ON = bool(on)
-    if not on:
-        _DEPTH_HINTS.clear()
-
-
-def new_depth_hints(V, W, H, device):
-    """A hint buffer for V views of a W x H image: every tile starts at 'no cut' (0xFFFFFFFF)."""
-    return torch.full((int(V), ((int(W) + 15) // 16) * ((int(H) + 15) // 16)), -1, dtype=torch.int32, device=device)
-
-
-def depth_hints_for(key, V, W, H, device):
-    """The hint buffer the library keeps for the views identified by `key` (None when hints are off)."""
-    if not _DEPTH_HINTS_ON:
-        return None
-    k = (key, int(V), int(W), int(H), str(device))
-    h = _DEPTH_HINTS.get(k)
-    if h is None:
-        if len(_DEPTH_HINTS) > 64:
-            _DEPTH_HINTS.clear()
-        h = _DEPTH_HINTS[k] = new_depth_hints(V, W, H, device)
-    return h
-
-
-def hint_stats():
-    a, b = C.c_longlong(0), C.c_longlong(0)
-    lib.gsr_hint_stats(C.byref(a), C.byref(b))
-    return dict(hinted_forwards=int(a.value), repeated=int(b.value))
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,

@@ -122,21 +122,6 @@ int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes,
                       void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered,
                       int resume, gsr_stream_t stream);
 
-/* gsr_forward_batch with per-(view, tile) DEPTH HINTS, for callers that render the same views again and again (a training loop over
- * a fixed set of cameras).  On a dense cloud 84 % of the sorted pairs are never read -- the render stops where the pixels saturate.
- * depth_hint [V][T] (device, T = ceil(W/16) ceil(H/16); in / out) holds, per tile, the view-space depth (float bits) up to which the
- * tile's list was consumed by the previous call with these hints, times (1 + slack); 0xFFFFFFFF = no cut (initialise the buffer with
- * it).  Pairs of Gaussians deeper than their tile's hint are left out of the sort and the lists.  A hint is NEVER trusted: if a tile
- * whose list was cut ends its walk with a live pixel, the call repeats its binning half without the filter before it returns, so
- * out_color, radii, num_rendered, final_T, n_contrib and every gradient of the backward that follows are the unhinted call's bit for
- * bit (only the private lists are shorter); the buffer then holds fresh hints either way.  The host waits for the END of a hinted
- * forward (it has to learn whether a cut list was outrun), not only for the pair counts.  depth_hint = NULL, resume = 1 or
- * reference_lists = 1: plain gsr_forward_batch.  gsr_hint_stats: hinted forwards so far, and how many had to repeat. */
-int gsr_forward_batch_hinted(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
-                             void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered,
-                             int resume, uint32_t* depth_hint, float slack, gsr_stream_t stream);
-void gsr_hint_stats(long long* calls, long long* repeats);
-
 /* gsr_forward_batch that also composites `nx` (4 or 8; pad with zero channels) extra per-Gaussian channels with the SAME alphas,
  * transmittances and stopping decisions as the colour: out_extra[v][k] = sum_i extra[v][i][k] * view_scale[v][k] * alpha_i * T_i +
  * T_final * bg_extra[k], term for term what a separate call with colors_precomp = those channels would produce -- the
