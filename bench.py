@@ -64,7 +64,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches (same guide)
 VALU_PEAK_GWIPS = 1228.9     # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
 
-STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>", "preprocess": "k_preprocess<1>",
+STAGE_KERNEL = {"render_backward": "k_render_backward<false>", "render_forward": "k_render_forward<0>", "preprocess": "k_preprocess<1>",
                 "preprocess_backward": "k_preprocess_backward<1>", "duplicate": "k_duplicate<unsigned short>"}
 
 

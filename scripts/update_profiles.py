@@ -47,7 +47,7 @@ if os.path.exists(cal):
             factor["_" + p[0]] = round(float(p[2]) / (float(p[3]) * 1024.0), 3)      # line bytes per counted byte
     if "_k_stream16" in factor:
         factor["default"] = factor["_k_stream16"]
-    for k in ("k_render_backward", "k_render_forward<0>"):
+    for k in ("k_render_backward<false>", "k_render_backward<true>", "k_render_forward<0>", "k_render_forward_half"):
         if "_k_gather36" in factor:
             factor[k] = factor["_k_gather36"]
     if "_k_gather16" in factor:
@@ -114,7 +114,7 @@ json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_
 # complete its roofline block from them, and say so
 rf = bench.get("roofline")
 if rf:
-    kn = {"render_backward": "k_render_backward", "render_forward": "k_render_forward<0>"}.get(rf["kernel"], rf["kernel"])
+    kn = {"render_backward": "k_render_backward<false>", "render_forward": "k_render_forward<0>"}.get(rf["kernel"], rf["kernel"])
     rf["traffic"] = out["bytes_per_launch"].get(kn)
     rf["traffic_source"] = ("filled in by scripts/update_profiles.py from the PMC passes of the SAME lease (profiles/pmc_traffic.json): "
                             "(%s x FETCH_SIZE + WRITE_SIZE) per launch" % factor.get(kn, factor["default"]))
@@ -133,6 +133,8 @@ if rf:
         rate = vi / (rf["avg_ms"] * 1e-3)
         rf["valu"] = {"wave_instructions": int(vi), "G_wave_instr_per_s": round(rate / 1e9, 1), "peak_G_wave_instr_per_s": 1228.9,
                       "frac": round(rate / 1e9 / 1228.9, 4), "source": "SQ_INSTS_VALU per launch (same lease); duration measured live"}
+        if "binding_frac" in rf and str(rf.get("binding_roof", "")).startswith("valu"):
+            rf["binding_frac"] = rf["valu"]["frac"]
     json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
 # context figure: the reference's own kernels (oracle/_ref, hipify-perl build) on the same GPU and view, scripts/compare_ref.py
 cr = os.path.join(src, "compare_ref.json")
