@@ -23,110 +23,70 @@ from . import _native as _C
 
 
 def cpu_deep_copy_tuple(input_tuple):
-    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
-    return tuple(copied_tensors)
+    """Host copies of every tensor of an argument tuple (what the debug snapshots store); other items pass through."""
+    return tuple(x.cpu().clone() if isinstance(x, torch.Tensor) else x for x in input_tuple)
 
 
-def rasterize_gaussians(
-    means3D,
-    means2D,
-    sh,
-    colors_precomp,
-    opacities,
-    scales,
-    rotations,
-    cov3Ds_precomp,
-    raster_settings,
-):
-    return _RasterizeGaussians.apply(
-        means3D,
-        means2D,
-        sh,
-        colors_precomp,
-        opacities,
-        scales,
-        rotations,
-        cov3Ds_precomp,
-        raster_settings,
-    )
+def _native_call(fn, args, debug, dump, message, **kw):
+    """One call into the native library.  With `debug` the arguments are copied to the host first, and if the call raises they are
+    written to `dump` with the reference's message before the exception travels on (reference __init__.py:83-90,132-139)."""
+    if not debug:
+        return fn(*args, **kw)
+    snapshot = cpu_deep_copy_tuple(args)
+    try:
+        return fn(*args, **kw)
+    except Exception:
+        torch.save(snapshot, dump)
+        print(message)
+        raise
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+def _or_none(grad, inp):
+    """an absent optional was passed as an empty tensor: its gradient slot gets None, not a [P, ...] tensor of the wrong shape
+    (autograd validates shapes on ROCm torch 2.x)"""
+    return grad if inp.numel() != 0 else None
 
 
 class _RasterizeGaussians(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
-        rs = raster_settings
-        # argument order of the native call = reference __init__.py:60-80
-        args = (
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug,
-        )
-        need_backward = any(ctx.needs_input_grad)
-        if rs.debug:
-            cpu_args = cpu_deep_copy_tuple(args)
-            try:
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
-                    *args, need_backward=need_backward)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_fw.dump")
-                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-                raise ex
-        else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(
-                *args, need_backward=need_backward)
+    """The per-view call: 9 inputs in the reference's order, (color, radii) out, gradients back in input order (reference
+    __init__.py:44-155)."""
 
-        ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
-        ctx.opacity_shape = tuple(opacities.shape)
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
-                              binningBuffer, imgBuffer)
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        # the native call's argument order = reference __init__.py:60-80
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+                rs.debug)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _native_call(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.", need_backward=any(ctx.needs_input_grad))
+        ctx.raster_settings, ctx.num_rendered, ctx.opacity_shape = rs, num_rendered, tuple(opacities.shape)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+                              imgBuffer)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
-        num_rendered = ctx.num_rendered
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
-
-        # argument order of the native call = reference __init__.py:109-129
-        args = (
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
-            geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.debug,
-        )
-        if rs.debug:
-            cpu_args = cpu_deep_copy_tuple(args)
-            try:
-                (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise ex
-        else:
-            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
-
-        # absent optionals were passed as empty tensors; their gradient slot gets None instead of a
-        # [P,...] tensor of the wrong shape (autograd validates shapes on ROCm torch 2.x)
-        def fit(g, inp):
-            return g if inp.numel() != 0 else None
-
-        grads = (
-            grad_means3D,
-            grad_means2D,
-            fit(grad_sh, sh),
-            fit(grad_colors_precomp, colors_precomp),
-            grad_opacities.reshape(ctx.opacity_shape),
-            fit(grad_scales, scales),
-            fit(grad_rotations, rotations),
-            fit(grad_cov3Ds_precomp, cov3Ds_precomp),
-            None,
-        )
-        return grads
+        # the native call's argument order = reference __init__.py:109-129
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
+                binningBuffer, imgBuffer, rs.debug)
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _native_call(
+            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump",
+            "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # gradients in the order of forward's inputs; the settings get none
+        return (g_means3D, g_means2D, _or_none(g_sh, sh), _or_none(g_colors, colors_precomp), g_opacities.reshape(ctx.opacity_shape),
+                _or_none(g_scales, scales), _or_none(g_rotations, rotations), _or_none(g_cov3D, cov3Ds_precomp), None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -157,37 +117,18 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
-        raster_settings = self.raster_settings
-
-        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        # exactly one colour source and exactly one covariance source (reference __init__.py:190-195: the same exception texts)
+        if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
-
-        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
-                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        pair_given, pair_complete = scales is not None or rotations is not None, scales is not None and rotations is not None
+        if (cov3D_precomp is None and not pair_complete) or (cov3D_precomp is not None and pair_given):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-
-        if shs is None:
-            shs = torch.Tensor([])
-        if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
-        if scales is None:
-            scales = torch.Tensor([])
-        if rotations is None:
-            rotations = torch.Tensor([])
-        if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
-
-        return rasterize_gaussians(
-            means3D,
-            means2D,
-            shs,
-            colors_precomp,
-            opacities,
-            scales,
-            rotations,
-            cov3D_precomp,
-            raster_settings,
-        )
+        # absent optionals travel as empty CPU tensors, like the reference's torch.Tensor([]) (:197-206)
+        absent = torch.Tensor([])
+        shs, colors_precomp, scales, rotations, cov3D_precomp = (absent if t is None else t
+                                                                 for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
 
 
 # ---- extension: all views of one cloud in ONE submission ----------------------------------------------------
