@@ -117,7 +117,16 @@ def test_backward_vs_oracle(name, oracle, gpu_device):
     p, gp = run_product(s, gpu_device, dL_dpix=dL)
     # only compare gradients when the forward bookkeeping the backward replays is identical
     if s.P and (p["n_contrib"] != o["n_contrib"]).any():
-        pytest.skip("forward threshold flip between glibc and ocml expf on this scene; covered vs the reference build")
+        # a threshold flip between glibc's and ocml's expf in the forward: the oracle's backward replays other decisions than the
+        # product's.  The test does not go quiet (no skip): the same gradients are held against the reference build instead, whose
+        # expf is the product's, and the flip is reported.
+        flips = int((p["n_contrib"] != o["n_contrib"]).sum())
+        print("test_backward_vs_oracle[%s]: %d pixels flip between glibc and ocml expf; compared with the reference build" % (name, flips))
+        _, gr = _ref("strict").forward_backward(s, dL)
+        gr = dict(gr)
+        gr["dL_dopacity"] = gr["dL_dopacity"].reshape(gp["dL_dopacity"].shape)
+        _check_grads(gp, gr, name + " (ref, after an expf flip against the oracle)")
+        return
     if s.P:
         np.testing.assert_array_equal(p["clamped"].astype(bool), o["clamped"].astype(bool))
     _check_grads(gp, go, name)
