@@ -157,6 +157,29 @@ __device__ __forceinline__ PairRec<NX> read_pair(const float* lds, int pair)
     return r;
 }
 
+// One surviving entry into its compacted slot of the staging area (both forward kernels): the nine values the pixels need and the
+// entry's 1-based list position, in the pair layout above.  The last survivor of an ODD count also fills its pair's second half with a
+// copy of itself at opacity 0 (alpha 0: the 1/255 test drops it).  Returns true for that lane (extra channels are copied likewise).
+__device__ __forceinline__ bool stage_entry(float* stage, int pw, uint32_t slot, uint32_t nsurv, const f32x4& c0, const f32x4& c1, float c2b,
+                                            uint32_t my_pos)
+{
+    float* p = stage + (slot >> 1) * pw + (slot & 1u);
+    p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
+    float* pc = stage + (slot >> 1) * pw + 12 + 2 * (slot & 1u);
+    pc[0] = c1.z; pc[1] = c1.w;
+    p[16] = c2b;
+    uint32_t* pp = (uint32_t*)p;
+    pp[18] = my_pos;
+    const bool lone = slot + 1 == nsurv && (slot & 1u) == 0;
+    if (lone) {
+        p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
+        pc[2] = c1.z; pc[3] = c1.w;
+        p[17] = c2b;
+        pp[19] = my_pos;
+    }
+    return lone;
+}
+
 #ifdef GSR_STATS
 // instrumentation build only: where the forward waves' time goes, summed over the waves of the launches since the last reset
 // (10-ns ticks): 0 whole life, 1 waiting for the next round's records at the rotation point, 2 footprint test + staging,
@@ -334,34 +357,14 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 const uint32_t nsurv = (uint32_t)__popcll(mask);
                 if (touch) {
-                    float* p = stage + (slot >> 1) * PW + (slot & 1u);
-                    p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
-                    float* pc = stage + (slot >> 1) * PW + 12 + 2 * (slot & 1u);
-                    pc[0] = c1.z; pc[1] = c1.w;
-                    p[16] = c2b;
-                    const uint32_t my_pos = (uint32_t)(base + (int)lane + 1);   // 1-based list position
-                    uint32_t* pp = (uint32_t*)p;
-                    pp[18] = my_pos;
-                    f32x4 e0 = cx0, e1 = cx1;
+                    const bool lone = stage_entry(stage, PW, slot, nsurv, c0, c1, c2b, (uint32_t)(base + (int)lane + 1));
                     if (NX > 0) {
+                        f32x4 e0 = cx0, e1 = cx1;
                         e0 *= xs0;            // times +-1 (or any per-view factor): one multiply per staged value, not per pixel
                         if (NX > 4) e1 *= xs1;
-                        float* px_ = stage + (slot >> 1) * PW + PAIR_WORDS + 2 * (slot & 1u);
-                        *(f32x2*)(px_ + 0) = f32x2{e0.x, e0.y};
-                        *(f32x2*)(px_ + 4) = f32x2{e0.z, e0.w};
-                        if (NX > 4) {
-                            *(f32x2*)(px_ + 8) = f32x2{e1.x, e1.y};
-                            *(f32x2*)(px_ + 12) = f32x2{e1.z, e1.w};
-                        }
-                    }
-                    if (slot + 1 == nsurv && (slot & 1u) == 0) {
-                        // odd count: the missing partner is a copy with opacity 0 -> alpha 0 -> the 1/255 test drops it
-                        p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
-                        pc[2] = c1.z; pc[3] = c1.w;
-                        p[17] = c2b;
-                        pp[19] = my_pos;
-                        if (NX > 0) {
-                            float* px_ = stage + (slot >> 1) * PW + PAIR_WORDS + 2;
+                        // (a lone last survivor's extra values go to both halves of its pair, like its colour)
+                        for (uint32_t h = slot & 1u; h < (lone ? 2u : (slot & 1u) + 1u); h++) {
+                            float* px_ = stage + (slot >> 1) * PW + PAIR_WORDS + 2 * h;
                             *(f32x2*)(px_ + 0) = f32x2{e0.x, e0.y};
                             *(f32x2*)(px_ + 4) = f32x2{e0.z, e0.w};
                             if (NX > 4) {
@@ -643,22 +646,7 @@ __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
                 const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                 const uint32_t nsurv = (uint32_t)__popcll(mask);
                 const int npairs = (int)((nsurv + 1u) >> 1);
-                if (touch) {
-                    float* p = stage + (slot >> 1) * PW + (slot & 1u);
-                    p[0] = c0.x; p[2] = c0.y; p[4] = c0.z; p[6] = c0.w; p[8] = c1.x; p[10] = c1.y;
-                    float* pc = stage + (slot >> 1) * PW + 12 + 2 * (slot & 1u);
-                    pc[0] = c1.z; pc[1] = c1.w;
-                    p[16] = c2b;
-                    const uint32_t my_pos = (uint32_t)(base + (int)lane + 1);
-                    uint32_t* pp = (uint32_t*)p;
-                    pp[18] = my_pos;
-                    if (slot + 1 == nsurv && (slot & 1u) == 0) {   // odd count: the partner is a copy with opacity 0
-                        p[1] = c0.x; p[3] = c0.y; p[5] = c0.z; p[7] = c0.w; p[9] = c1.x; p[11] = 0.f;
-                        pc[2] = c1.z; pc[3] = c1.w;
-                        p[17] = c2b;
-                        pp[19] = my_pos;
-                    }
-                }
+                if (touch) stage_entry(stage, PW, slot, nsurv, c0, c1, c2b, (uint32_t)(base + (int)lane + 1));
                 // an odd number of PAIRS: the upper half's record of the last step is a pair of opacity 0 (alpha 0: never counted)
                 if ((npairs & 1) && lane < (uint32_t)PW) stage[npairs * PW + lane] = 0.f;
                 const int nsteps = (npairs + 1) >> 1;
