@@ -104,6 +104,9 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+_ABSENT = torch.Tensor([])
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -123,8 +126,9 @@ class GaussianRasterizer(nn.Module):
         pair_given, pair_complete = scales is not None or rotations is not None, scales is not None and rotations is not None
         if (cov3D_precomp is None and not pair_complete) or (cov3D_precomp is not None and pair_given):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        # absent optionals travel as empty CPU tensors, like the reference's torch.Tensor([]) (:197-206)
-        absent = torch.Tensor([])
+        # absent optionals travel as empty CPU tensors, like the reference's torch.Tensor([]) (:197-206); one shared empty tensor
+        # instead of a fresh one per call (this method runs while the GPU waits for the call's first kernel)
+        absent = _ABSENT
         shs, colors_precomp, scales, rotations, cov3D_precomp = (absent if t is None else t
                                                                  for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
@@ -274,7 +278,7 @@ def rasterize_views(means3D, means2D, opacities, settings_list, shs=None, colors
     if ((scales is None or rotations is None) and cov3D_precomp is None) or (
             (scales is not None or rotations is not None) and cov3D_precomp is not None):
         raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-    e = torch.Tensor([])
+    e = _ABSENT
     return _RasterizeGaussiansViews.apply(
         means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
         e if scales is None else scales, e if rotations is None else rotations, e if cov3D_precomp is None else cov3D_precomp,

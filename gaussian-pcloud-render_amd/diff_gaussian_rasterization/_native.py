@@ -126,7 +126,44 @@ def _f32c(t, device, name):
         return t
     if t.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float but found %s for %s" % (t.dtype, name))
+    if t.device == device and t.is_contiguous():     # the usual case: nothing to dispatch
+        return t
     return t.to(device).contiguous()
+
+
+# the current stream's handle and "is `device` the current device" without building torch.cuda.Stream / device objects: this
+# module's code runs between the caller's last host->device copy and the first kernel launch, i.e. while the GPU idles whenever
+# the caller's loop drains the stream once per frame (the reference's does: simple_raw_render.py:260-263 builds the settings
+# tensors from host arrays for every call)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_handle(device):
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    @staticmethod
+    def give(*tensors):
+        return tensors[0] if len(tensors) == 1 else tensors
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def _on_device(device):
+    """context that makes `device` the current HIP device (nothing to do when it already is)"""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_CONTEXT
+    return torch.cuda.device(device)
 
 
 def _require_hip(device):
@@ -139,24 +176,16 @@ def _require_hip(device):
 def _params(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
             tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug, need_backward):
     device = means3D.device
-    keep = dict(
-        bg=_f32c(bg, device, "bg"), means3D=_f32c(means3D, device, "means3D"), shs=_f32c(sh, device, "sh"),
-        colors_precomp=_f32c(colors, device, "colors_precomp"), opacities=_f32c(opacity, device, "opacities"),
-        scales=_f32c(scales, device, "scales"), rotations=_f32c(rotations, device, "rotations"),
-        cov3D_precomp=_f32c(cov3D_precomp, device, "cov3D_precomp"),
-        viewmatrix=_f32c(viewmatrix, device, "viewmatrix"), projmatrix=_f32c(projmatrix, device, "projmatrix"),
-        campos=_f32c(campos, device, "campos"),
-    )
-    p = GsrParams()
-    p.P = means3D.shape[0]
-    p.D = int(degree)
-    p.M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0  # rasterize_points.cu:83-87
-    p.W, p.H = int(W), int(H)
-    p.tanfovx, p.tanfovy, p.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
-    p.prefiltered, p.debug, p.need_backward = int(bool(prefiltered)), int(bool(debug)), int(bool(need_backward))
-    p.reference_lists = int(reference_lists())
-    for k, t in keep.items():
-        setattr(p, k, _ptr(t))
+    # (the converted tensors are returned so that they outlive the enqueued kernels' use of their pointers)
+    keep = (_f32c(bg, device, "bg"), _f32c(means3D, device, "means3D"), _f32c(sh, device, "sh"),
+            _f32c(colors, device, "colors_precomp"), _f32c(opacity, device, "opacities"), _f32c(scales, device, "scales"),
+            _f32c(rotations, device, "rotations"), _f32c(cov3D_precomp, device, "cov3D_precomp"),
+            _f32c(viewmatrix, device, "viewmatrix"), _f32c(projmatrix, device, "projmatrix"), _f32c(campos, device, "campos"))
+    M = int(sh.shape[1]) if sh.numel() != 0 and sh.shape[0] != 0 else 0  # rasterize_points.cu:83-87
+    # field order of GsrParams / gsr_params (include/gsr.h)
+    p = GsrParams(means3D.shape[0], int(degree), M, int(W), int(H), float(tan_fovx), float(tan_fovy), float(scale_modifier),
+                  int(bool(prefiltered)), int(bool(debug)), int(bool(need_backward)), int(reference_lists()),
+                  *[_ptr(t) for t in keep])
     return p, keep
 
 
@@ -203,6 +232,30 @@ def _note_counts(key, counts):
 
 def reset_capacity_hints():
     _CAP_HINT.clear()
+
+
+# arena sizes are functions of (P, need_backward) resp. (W, H) alone: asked of the library once per configuration
+_ARENA_BYTES, _IMAGE_BYTES = {}, {}
+
+
+def _arena_bytes(P, need_backward):
+    k = (P, bool(need_backward))
+    b = _ARENA_BYTES.get(k)
+    if b is None:
+        if len(_ARENA_BYTES) > 256:
+            _ARENA_BYTES.clear()
+        b = _ARENA_BYTES[k] = int(lib.gsr_geom_bytes(P) if need_backward else lib.gsr_geom_bytes_inference(P))
+    return b
+
+
+def _image_bytes(W, H):
+    k = (W, H)
+    b = _IMAGE_BYTES.get(k)
+    if b is None:
+        if len(_IMAGE_BYTES) > 256:
+            _IMAGE_BYTES.clear()
+        b = _IMAGE_BYTES[k] = int(lib.gsr_image_bytes(W, H))
+    return b
 
 
 
@@ -312,9 +365,9 @@ class _OnSideStream:
     """Context of one forward call: inside, torch's current stream is a side stream that waits only for the call's inputs;
     leaving it, the caller's stream is ordered behind the side stream and takes over the outputs handed to `give`."""
 
-    def __init__(self, device, tensors, enabled=True):
+    def __init__(self, device, tensors):
         self.device, self.active, self.out = device, False, []
-        if not enabled or not _OVERLAP_ON or device.type != "cuda":
+        if device.type != "cuda":
             return
         self.cur = torch.cuda.current_stream(device)
         key = (device.index if device.index is not None else torch.cuda.current_device(), self.cur.cuda_stream)
@@ -388,27 +441,29 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     # stream that waits for the inputs only (see _OnSideStream); the caller's stream takes the results over when the block ends
     # (only calls of up to OVERLAP_MAX_VIEWS views: a 12-view batch has no tail for the next call's front end to hide behind, and
     # running the two side by side costs 2.5 % on short bursts -- gpurun_out/r4k: 1 754 vs 1 711 frames/s at 20 frames per block)
-    ov = _OnSideStream(device, [background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrices, projmatrices,
-                                sh, camposs, xv, xs, xb], enabled=V <= OVERLAP_MAX_VIEWS)
-    with torch.cuda.device(device), ov:
-        viewmatrices = viewmatrices.reshape(-1, 4, 4)
-        projmatrices = projmatrices.reshape(-1, 4, 4)
-        camposs = camposs.reshape(-1, 3)
+    if _OVERLAP_ON and V <= OVERLAP_MAX_VIEWS:
+        ov = _OnSideStream(device, [background, means3D, colors, opacity, scales, rotations, cov3D_precomp, viewmatrices, projmatrices,
+                                    sh, camposs, xv, xs, xb])
+    else:
+        ov = _NO_CONTEXT
+    with _on_device(device), ov:
         if nx:
             xv = _f32c(xv, device, "extra")
             xb = _f32c(xb.reshape(-1), device, "bg_extra")
             xs = None if xs is None else _f32c(xs, device, "extra_view_scale")
-        out_extra = torch.empty((V, nx, H, W), dtype=torch.float32, device=device) if nx else None
+        f32 = dict(dtype=torch.float32, device=device)
+        out_extra = torch.empty((V, nx, H, W), **f32) if nx else None
         # every pixel and every radius is written by the kernels (the reference fills both with zeros first)
-        out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=device)
+        out_color = torch.empty((V, 3, H, W), **f32)
         radii = torch.empty((V, P), dtype=torch.int32, device=device)
-        stream = torch.cuda.current_stream(device).cuda_stream
+        stream = _stream_handle(device)
+        # (the matrices go over as pointers: [V,4,4] / [V,16] / [4,4] are the same 16 V floats once contiguous)
         p, keep = _params(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                           viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, prefiltered, debug,
                           need_backward)
         # the 64-B per-Gaussian gradient records are only carved for calls a backward may follow
-        geom = torch.empty((V * (lib.gsr_geom_bytes(P) if need_backward else lib.gsr_geom_bytes_inference(P)),), **byte)
-        img = torch.empty((V * lib.gsr_image_bytes(W, H),), **byte)
+        geom = torch.empty((V * _arena_bytes(P, need_backward),), **byte)
+        img = torch.empty((V * _image_bytes(W, H),), **byte)
         counts = (C.c_int64 * V)()
         if capacity is None:
             hint = _CAP_HINT.get(key)
@@ -517,10 +572,10 @@ def rasterize_gaussians_backward_batch(background, means3D, radii, colors, scale
     dL_dscales = e_or_z((P, 3), **z) if has_sr else torch.zeros((P, 3), **z)
     dL_drotations = e_or_z((P, 4), **z) if has_sr else torch.zeros((P, 4), **z)
     if P != 0:
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
-            opacity_unused = torch.empty((1,), **z)  # opacity lives in the geom arena; pointer only has to be non-NULL
-            p, keep = _params(background, means3D, colors, opacity_unused, scales, rotations, scale_modifier,
+        with _on_device(device):
+            stream = _stream_handle(device)
+            # (opacity lives in the geom arena; the pointer only has to be non-NULL: means3D stands in)
+            p, keep = _params(background, means3D, colors, means3D, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrices, projmatrices, tan_fovx, tan_fovy, H, W, sh, degree, camposs, False,
                               debug, True)
             dpix = _f32c(dL_dout_color, device, "dL_dout_color")
