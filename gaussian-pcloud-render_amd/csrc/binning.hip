@@ -415,9 +415,18 @@ int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_k
 }
 
 // ---- render launch order: tiles by descending work estimate (128 quarter-octave buckets) -------------
-// Per-tile work is (entries walked) x 256 pixels and the spread is 5-10x; dispatching the
-// heavy tiles first keeps the tail of the forward render kernel short (it only knows the list length).
-// Any permutation is correct.
+// Dispatching the heavy tiles first keeps the tail of the forward render kernel short.  Any permutation is correct.
+// What a tile costs is the number of entries its pixels evaluate before they saturate, which is NOT its list length: a list
+// consumed to its end costs its length, but the denser a tile, the sooner its pixels saturate -- on the benchmark views the waves
+// that evaluate most (150-300 steps of four entries) sit on lists of 1 500-4 000 entries, lists of 12 000+ cost half of that
+// (scripts/debug/fwd_half_tail.py).  Ordered by length, those medium lists queue behind every longer one and start when the launch is
+// half over: a single view's forward ended on them at 0.22 ms although no wave lives longer than 0.15.  The estimate is the length up
+// to a knee and falls slowly beyond it: w(L) = L for L <= K, K (K / L)^e above (K = 2 048, e = 0.3: the means per length bucket of
+// two benchmark views fall like e = 0.6, but the lists that are walked to their end -- silhouette tiles, some pixel never saturates --
+// are the heavy ones of their length and should not queue late; GSR_ORDER_KNEE / GSR_ORDER_EXP in the environment, knee 0 = plain
+// length).  Measured (leases r5t / r5u): single-view forward 0.221-0.223 -> 0.209-0.217 ms, in a 12-view batch 0.123 -> 0.119-0.122 per
+// view; the instrumented launch 211 -> 192 us against 131 us of summed wave time per slot: what is left is the spread INSIDE a length
+// class (a wave lives up to 0.16 ms of a 0.19 ms launch), which only the render itself could tell.
 constexpr int ORD_BUCKETS = 128;
 
 __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
@@ -432,8 +441,14 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 // One 1024-thread workgroup per view: LDS histogram, scan, LDS cursors.  (T is 8 160 at 1080p, 32 400 at 4K.)  Lanes of a
 // wave that fall in the same bucket are aggregated with a ballot so the thousands of empty tiles, which all share
 // one bucket, cost one LDS atomic per wave instead of 64 serialized ones.
+__device__ __forceinline__ uint32_t work_estimate(uint32_t len, float knee, float expo)
+{
+    if (knee <= 0.f || (float)len <= knee) return len;
+    return (uint32_t)(knee * __powf(knee / (float)len, expo));
+}
+
 __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
-                                                     size_t iv_stride)
+                                                     size_t iv_stride, float knee, float expo)
 {
     ranges = at_view(ranges, iv_stride, blockIdx.x);
     tile_order = at_view(tile_order, iv_stride, blockIdx.x);
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
         for (int t = threadIdx.x; t < T_pad; t += 1024) {
             const bool ok = t < T;
             uint32_t b = 0;
-            if (ok) b = work_bucket(ranges[t].y - ranges[t].x);
+            if (ok) b = work_bucket(work_estimate(ranges[t].y - ranges[t].x, knee, expo));
             const bool empty = ok && b == ORD_BUCKETS - 1;
             const uint64_t em = __ballot(empty);
             uint32_t slot = 0;
@@ -485,7 +500,9 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
 
 int launch_tile_order(const Launch& L, const Batch& B, int T)
 {
-    hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride);
+    static const float knee = [] { const char* e = getenv("GSR_ORDER_KNEE"); return e ? (float)atof(e) : 2048.f; }();
+    static const float expo = [] { const char* e = getenv("GSR_ORDER_EXP"); return e ? (float)atof(e) : 0.3f; }();
+    hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride, knee, expo);
     return check_launch(L, "tile_order");
 }
 

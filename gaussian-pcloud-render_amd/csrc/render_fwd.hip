@@ -19,8 +19,8 @@
 //     evaluated, so the dependent id -> record gather latency is off the critical path;
 //   - per-pixel skips are selects; the only branches are wave-uniform (mask empty, all 64 pixels done).
 // The duration of this kernel is set by the quadrants that walk deepest (a wave walks its list serially, one
-// instruction per ~5.5 cycles when it has its SIMD to itself); tiles are dispatched in descending list-length order
-// (tile_order).  With need_backward the per-pixel (T, C) state is left at every BWD_CHUNK-entry boundary a quadrant
+// instruction per ~5.5 cycles when it has its SIMD to itself); tiles are dispatched by descending work estimate
+// (binning.hip k_tile_order).  With need_backward the per-pixel (T, C) state is left at every BWD_CHUNK-entry boundary a quadrant
 // crosses, so that the backward pass can work on slices of lists (render_bwd.hip).
 //
 // k_render_forward<NX>, NX = 4 or 8: the same walk also composites NX extra per-Gaussian channels with the colour's alphas
@@ -561,6 +561,10 @@ __device__ __forceinline__ void swap_halves2(float& a_lo, float& a_hi, float& b_
 
 __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
 {
+#ifdef GSR_STATS
+    FW_T(tw0);
+    unsigned long long tw_wait = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_pairs = 0;   // (n_pairs: steps of four entries here)
+#endif
     constexpr int PW = PAIR_WORDS;
     // workgroup b runs on XCD b % 8: the eight half-quadrants of one tile are b, b + 8, ..., b + 56 (one L2 fetch of list and records);
     // groups of 64 workgroups (8 tiles x 8 halves) are dealt to the views round-robin like the 8 x 8 kernel's groups of 32
@@ -639,6 +643,10 @@ __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
                 if (eg == 0) a.ckpt[slot * 256 + q * 64 + hf * 32u + pl] = make_float4(T, C01.x, C01.y, C2);
                 crossed = true;
             }
+#ifdef GSR_STATS
+            FW_T(ts0);
+            n_rounds++;
+#endif
             const bool valid = base + (int)lane < total;
             const bool touch = valid && may_touch_rect(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx0, by0, bx1, by1);
             const uint64_t mask = __ballot(touch);
@@ -738,6 +746,10 @@ __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
                     }
                 };
                 int step = 0;
+#ifdef GSR_STATS
+                FW_T(ts1);
+                tw_stage += ts1 - ts0;
+#endif
                 StepRec ra = load_step(0), rb;
                 for (;;) {
                     rb = load_step(step + 1);
@@ -747,14 +759,34 @@ __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)
                     eval_step(rb);
                     if (all_done || ++step >= nsteps) break;
                 }
+#ifdef GSR_STATS
+                { FW_T(ts2); tw_eval += ts2 - ts1; n_pairs += (unsigned long long)step + 1ull; }
+#endif
             }
+#ifdef GSR_STATS
+            FW_T(ts3);
+#endif
             retire_prefetch(n0, n1, n2b, id_nn);
+#ifdef GSR_STATS
+            { FW_T(ts4); tw_wait += ts4 - ts3; }
+#endif
             if (all_done) break;
             c0 = n0; c1 = n1; c2b = n2b;
             id_cur = id_nxt;
             id_nxt = id_nn;
         }
     }
+#ifdef GSR_STATS
+    // (record layout of the 8 x 8 kernel; word 6 counts steps, word 7 is the tile's list length: scripts/debug/fwd_half_tail.py)
+    if (lane == 0 && blockIdx.x < (unsigned)FW_REC) {
+        FW_T(tw1);
+        unsigned* r_ = g_fwd_rec[blockIdx.x];
+        r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_stage; r_[3] = (unsigned)tw_eval;
+        r_[4] = 1u; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_pairs; r_[7] = (unsigned)total;
+        g_fwd_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492) | (__builtin_amdgcn_s_getreg(63508) << 28);   // HW_ID, XCC_ID
+        g_fwd_hw[blockIdx.x][1] = (unsigned)tw0;
+    }
+#endif
     {
         uint32_t need = inside ? (done ? stop_at : (uint32_t)total) : 0u;
 #pragma unroll
