@@ -11,7 +11,7 @@ RCCL, one collective per submission, on a stream of its own (weak scaling).  All
 HEADLINE call shape (`config.workload` says so): frames are submitted --views-per-call (default 12, one turn of the circle) at a
 time through rasterize_views -- the C ABI's gsr_forward_batch / gsr_backward_batch: every kernel covers all views of the
 submission, nothing on the host waits for the device inside a frame, gradients of the shared cloud are summed over the views on
-the device -- with --streams (default 2) submissions in flight on their own HIP streams.  K steps that are not a multiple of the
+the device -- with --streams (default 1) submissions in flight on their own HIP streams.  K steps that are not a multiple of the
 batch end with a smaller batch.  The timed region is `--repeats` (default 5) blocks of exactly K steps, every block bracketed by
 barrier + synchronize; `value` / `ms_per_step` are the MEDIAN block (max over ranks per block), all blocks are listed.
 
@@ -186,8 +186,9 @@ def main():
     ap.add_argument("--no-cpu-1core", action="store_true", help="skip the 1-core CPU figure (about a minute of CPU time)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSR_BENCH_STREAMS", "0")),
                     help="host threads per rank, each rendering whole submissions on its own HIP stream (views are independent); "
-                         "0 = 2 when a timed block holds at least four submissions, else 1 (a second submission in flight is worth "
-                         "+1 %% on long blocks and costs 5 %% on a block of two submissions: the batched kernels have no tail to hide)")
+                         "0 = 1: one submission in flight (a second one is worth +-2 %%, box noise -- the batched kernels have no tail to "
+                         "hide -- and makes the in-region hipEvent duration of a kernel include whatever the other stream interleaves: "
+                         "2.39-2.81 ms for a kernel whose own trace says 2.29)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device-index 0 lets several ranks share one GPU to exercise the multi-rank control flow "
                          "(frames then travel through host memory; not a performance mode)")
@@ -247,7 +248,7 @@ def main():
     if args.views_per_call <= 0:
         args.views_per_call = n_views if shard == "circle" else max(1, len(range(rank, n_views, world)))
     if args.streams <= 0:
-        args.streams = 2 if args.steps >= 4 * max(1, args.views_per_call) else 1
+        args.streams = 1
     # the reference's circle cameras (simple_raw_render.py:259-278 loops over them); configs[3] / [4] use 8 of them
     views = camera.circle_views(n_imgs=n_views, fov_deg=45.0, width_px=W, height_px=H)
     bg = torch.ones(3, device=dev)  # simple_benchmark.py:332 background (1,1,1)
