@@ -444,7 +444,8 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t len)
 __device__ __forceinline__ uint32_t work_estimate(uint32_t len, float knee, float expo)
 {
     if (knee <= 0.f || (float)len <= knee) return len;
-    return (uint32_t)(knee * __powf(knee / (float)len, expo));
+    // (v_log_f32 / v_exp_f32: a scheduling hint needs no accurate pow -- the library call made this kernel 10 us longer)
+    return (uint32_t)(knee * __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(knee / (float)len)));
 }
 
 __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
