@@ -681,6 +681,7 @@ __attribute__((visibility("default"))) int gsr_debug_scatter_times(unsigned long
 __attribute__((visibility("default"))) int gsr_debug_fwd_times(unsigned long long* out8, int reset) { return gsr::debug_fwd_times(out8, reset); }
 __attribute__((visibility("default"))) int gsr_debug_fwd_records(unsigned* out, int n) { return gsr::debug_fwd_records(out, n); }
 __attribute__((visibility("default"))) int gsr_debug_bwd_times(unsigned long long* out8, int reset) { return gsr::debug_bwd_times(out8, reset); }
+__attribute__((visibility("default"))) int gsr_debug_bwd_records(unsigned* out, int n) { return gsr::debug_bwd_records(out, n); }
 __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long long* out8, int reset) { return gsr::debug_dup_times(out8, reset); }
 #endif
 

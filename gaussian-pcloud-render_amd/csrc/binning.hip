@@ -530,6 +530,7 @@ __global__ __launch_bounds__(1024) void k_bwd_items(int T, int chunk_shift, cons
     need = at_view(need, iv_stride, blockIdx.x);
     items = at_view(items, iv_stride, blockIdx.x);
     count = at_view(count, iv_stride, blockIdx.x);
+    if (threadIdx.x < 8) count[BWD_QUEUE_WORD + threadIdx.x] = 0;   // the render backward's work-unit counters of this view, one per XCD
     __shared__ uint32_t cnt[ORD_BUCKETS];
     __shared__ uint32_t cur[ORD_BUCKETS];
     const uint32_t lane = threadIdx.x & 63;

@@ -122,6 +122,7 @@ constexpr int BWD_CHUNK_SHIFT_MIN = 9;     // the binning arena's boundary-state
 #endif
 __host__ __device__ inline int bwd_chunk_shift(int V) { return V >= GSR_CHUNK_V ? 10 : 9; }
 constexpr int BWD_MAX_CHUNKS = 32;   // per tile; the last one takes whatever is left
+constexpr int BWD_QUEUE_WORD = 8;    // ImageView::bwd_count
 constexpr int BWD_TILE_BITS = 27;    // item = tile | chunk << 27 (check_params limits images to 2^27 tiles)
 
 // The binning arena is carved by CAPACITY (pairs), not by the frame's pair count: the count only exists on the device
@@ -140,7 +141,8 @@ struct BinView {
 
 struct ImageView {
     uint32_t* tile_need;  // [T] entries walked by the forward render  } cleared by k_preprocess at the start of
-    uint32_t* bwd_count;  // [4] number of backward items              } every frame
+    uint32_t* bwd_count;  // [16] [0] number of backward items         } every frame
+                          //      words BWD_QUEUE_WORD .. + 7: the render backward's work-unit counters of the view, one per XCD (zeroed by k_bwd_items)
     uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
@@ -223,7 +225,7 @@ inline ImageView image_view(void* base, int W, int H)
     const size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * (size_t)((H + TILE_Y - 1) / TILE_Y);
     v.zero_begin = cur;
     carve(cur, v.tile_need, T ? T : 1);
-    carve(cur, v.bwd_count, (size_t)4);
+    carve(cur, v.bwd_count, (size_t)16);
     v.zero_bytes = (size_t)(cur - v.zero_begin);
     carve(cur, v.ranges, T ? T : 1);
     carve(cur, v.final_T, N ? N : 1);
@@ -332,6 +334,7 @@ int debug_scatter_times(unsigned long long* out8, int reset);
 int debug_fwd_times(unsigned long long* out8, int reset);
 int debug_fwd_records(unsigned* out, int n);
 int debug_bwd_times(unsigned long long* out8, int reset);
+int debug_bwd_records(unsigned* out, int n);
 #endif
 // preprocess_bwd.hip
 // reads grad_rec of every view; writes the user-facing gradients summed over the views of the batch

@@ -286,6 +286,15 @@ __device__ unsigned long long g_bwd_stats[8];
 constexpr int BW_REC = 1 << 17;
 __device__ unsigned g_bwd_rec[BW_REC][8];
 #define BW_T(var) const unsigned long long var = wall_clock64()
+// raw per-workgroup records of the last launch, eight words each (scripts/debug/bwd_tail.py)
+int debug_bwd_records(unsigned* out, int n)
+{
+    static unsigned host[BW_REC][8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_rec), sizeof(host)) != hipSuccess) return -1;
+    if (n > BW_REC) n = BW_REC;
+    for (int r = 0; r < n; r++) for (int i = 0; i < 8; i++) out[r * 8 + i] = host[r][i];
+    return n;
+}
 int debug_bwd_times(unsigned long long* out8, int reset)
 {
     static unsigned host[BW_REC][8];
@@ -293,7 +302,7 @@ int debug_bwd_times(unsigned long long* out8, int reset)
     for (int i = 0; i < 8; i++) out8[i] = 0;
     unsigned long long longest = 0, waves = 0;
     for (int r = 0; r < BW_REC; r++) {
-        for (int i = 0; i < 8; i++) out8[i] += host[r][i];
+        for (int i = 0; i < 8; i++) if (i != 5) out8[i] += host[r][i];
         if (host[r][0] > longest) longest = host[r][0];
         if (host[r][0] != 0) waves++;
     }
@@ -323,6 +332,7 @@ struct RenderBwdArgs {
     float* grad_rec;     // [P][GRAD_REC_WORDS] accumulation records (common.hpp)
     uint64_t* counters;  // per view (CNT_*)
     uint32_t V;
+    uint32_t dynamic;    // work units are pulled from per-XCD counters (see the item loop)
     size_t g_stride, b_stride, iv_stride, gr_stride;
 };
 
@@ -332,12 +342,11 @@ template <bool SUBQ>
 __attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
-    // Work items are (tile, chunk of BWD_CHUNK consumed list entries); a workgroup takes every (gridDim/32 * 8)-th item.
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the four quadrant waves of one item
-    // are workgroups b, b+8, b+16, b+24: same XCD, dispatched together, and the item's list slice and Splat records
-    // are fetched into that L2 once instead of four times.
-    // Batches: groups of 32 workgroups are dealt to the views round-robin (see render_fwd.hip).
-    const uint32_t group = blockIdx.x >> 5, view = group % a.V, groups_per_view = (gridDim.x >> 5) / a.V;
+    // Work items are (tile, chunk of BWD_CHUNK consumed list entries), one quadrant per wave; which ones a workgroup takes: see the
+    // item loop.  XCD-aware either way: workgroup b runs on XCD b % 8 (each XCD has its own L2) and the four quadrant waves of an item
+    // run on one XCD at about the same time, so the item's list slice and Splat records are fetched into that L2 once instead of
+    // four times.  Batches: groups of 32 workgroups are dealt to the views round-robin (see render_fwd.hip).
+    const uint32_t group = blockIdx.x >> 5, view = group % a.V;
     a.ranges = at_view(a.ranges, a.iv_stride, view);
     a.items = at_view(a.items, a.iv_stride, view);
     a.accum = at_view(a.accum, a.iv_stride, view);
@@ -378,14 +387,33 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
     BW_T(tw0);
     unsigned long long tw_wait = 0, tw_setup = 0, tw_stage = 0, tw_eval = 0, n_rounds = 0, n_groups = 0, n_items_done = 0;
 #endif
-  for (uint32_t item_idx = (group / a.V) * 8u + (blockIdx.x & 7u); item_idx < n_items; item_idx += groups_per_view * 8u) {
+  // Which items a workgroup takes.  STATIC (a.dynamic == 0; the launch has a quartet of workgroups per eight items or more): quartet
+  // (b, b + 8, b + 16, b + 24) takes item (group / V) * 8 + b % 8 and every (groups per view * 8)-th after it, one quadrant each -- with
+  // at least as many quartets as items that is one item per quartet in dispatch order, heaviest first.  DYNAMIC (batches, whose grid
+  // would otherwise be capped far below the item count): every workgroup PULLS (item, quadrant) units of its view from the counter
+  // of its XCD until none is left (the counter hands out the items with index % 8 == XCD, quadrant by quadrant), so whatever slot
+  // falls free takes the heaviest unit left instead of a fixed every-n-th one, and the launch holds two workgroups per wave slot.
+  // (Not for single views: 1 280 waves pulling from one address wait for the counter -- 0.39 instead of 0.25 ms, lease r5x.)
+  uint32_t* const queue = const_cast<uint32_t*>(at_view(a.item_count, a.iv_stride, view)) + BWD_QUEUE_WORD + (blockIdx.x & 7u);
+  const uint32_t static_stride = ((gridDim.x >> 5) / a.V) * 8u;
+  uint32_t item_idx = (group / a.V) * 8u + (blockIdx.x & 7u) - static_stride, q = (blockIdx.x >> 3) & 3u;
+  for (;;) {
+    if (a.dynamic) {
+        uint32_t unit = 0;
+        if (threadIdx.x == 0) unit = atomicAdd(queue, 1u);
+        unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+        item_idx = (unit >> 2) * 8u + (blockIdx.x & 7u);
+        q = unit & 3u;
+    } else {
+        item_idx += static_stride;
+    }
+    if (item_idx >= n_items) break;
 #ifdef GSR_STATS
     BW_T(ti0);
     n_items_done++;
 #endif
     const uint32_t item = a.items[item_idx];
     const uint32_t tile = item & ((1u << BWD_TILE_BITS) - 1u), chunk = item >> BWD_TILE_BITS;
-    const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
     const uint32_t tx = tile % (uint32_t)a.gridx, ty = tile / (uint32_t)a.gridx;
     const uint32_t x0 = tx * TILE_X + (q & 1u) * 8u, y0 = ty * TILE_Y + (q >> 1) * 8u;
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
         BW_T(tw1);
         unsigned* r_ = g_bwd_rec[blockIdx.x];
         r_[0] = (unsigned)(tw1 - tw0); r_[1] = (unsigned)tw_wait; r_[2] = (unsigned)tw_setup; r_[3] = (unsigned)tw_stage;
-        r_[4] = (unsigned)tw_eval; r_[5] = (unsigned)n_rounds; r_[6] = (unsigned)n_groups; r_[7] = (unsigned)n_items_done;
+        r_[4] = (unsigned)tw_eval; r_[5] = (unsigned)tw0; r_[6] = (unsigned)n_groups; r_[7] = (unsigned)n_items_done;   // (5: start tick)
     }
 #endif
 }
@@ -816,14 +844,16 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
     a.chunk_shift = B.chunk_shift();
     a.V = (uint32_t)B.V;
     a.g_stride = B.g_stride; a.b_stride = B.b_stride; a.iv_stride = B.iv_stride;
-    // the number of items is only known on the device: every view gets the same number of workgroup quartets, enough in
-    // total to fill the chip's wave slots several times over, and they walk the view's item list with a stride
+    // the number of items is only known on the device.  A quartet of workgroups per eight tiles covers the items of a single view one
+    // to one (rarely more items than tiles); a batch would need V times that, so its workgroups -- about two per wave slot of the chip
+    // (five waves per SIMD, four SIMDs per CU), dealt to the views in groups of 32 -- pull work units until their view's queues are empty
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     int64_t groups = div_up(a.num_tiles, 8);
 #ifndef GSR_BWD_FILL
 #define GSR_BWD_FILL 4096
 #endif
-    const int64_t fill = div_up(GSR_BWD_FILL, B.V);        // 4096 groups x 32 single-wave workgroups = 25 per wave slot (measured: 1280 / 2048 / 2560 / 4096 / 8192 groups -> 0.216 / 0.213 / 0.211 / 0.210 / 0.221 ms per view)
-    if (groups > fill) groups = fill;
+    a.dynamic = groups * B.V > GSR_BWD_FILL ? 1u : 0u;
+    if (a.dynamic) groups = div_up((int64_t)cus * 4 * 5 * 2, 32 * (int64_t)B.V);
     if (groups < 8) groups = 8;
     if (backward_subquadrant_moments(-1))
         hipLaunchKernelGGL(k_render_backward<true>, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);

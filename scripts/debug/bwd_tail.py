@@ -31,3 +31,20 @@ for V in (1, 12):
     k = prof["render_backward"]
     print("V=%d: kernel %.3f ms; %d waves ran, %d items; summed wave time %.1f ms = %.3f ms per slot of 5120; longest wave %.3f ms; wait %.1f setup %.1f stage %.1f eval %.1f ms"
           % (V, k, waves, items, life * 1e-5, life * 1e-5 / 5120, longest * 1e-5, wait * 1e-5, setup * 1e-5, stage * 1e-5, ev * 1e-5))
+    # timeline of the launch: how many workgroups (= waves) are alive over time, when the longest ones started
+    n = 1 << 17
+    buf = (C.c_uint * (n * 8))()
+    N.lib.gsr_debug_bwd_records.argtypes = [C.POINTER(C.c_uint), C.c_int]
+    got = N.lib.gsr_debug_bwd_records(buf, n)
+    r = np.frombuffer(buf, dtype=np.uint32).reshape(n, 8)[:got]
+    r = r[r[:, 0] != 0]
+    life = r[:, 0].astype(np.float64) * 0.01
+    start = (r[:, 5] - r[:, 5].min()).astype(np.uint32).astype(np.float64) * 0.01
+    end = start + life
+    step = k * 1e3 / 10
+    print("   alive at t = " + ", ".join("%.0f us: %d" % (t, ((start <= t) & (end > t)).sum()) for t in np.arange(0.5, 10.5) * step))
+    print("   not yet started at those times: " + ", ".join("%d" % (start > t).sum() for t in np.arange(0.5, 10.5) * step))
+    top = np.argsort(-end)[:6]
+    for i in top:
+        print("   ends last: start %.1f life %.1f end %.1f us; groups %d items %d; eval %.1f stage %.1f setup %.1f us" % (start[i], life[i], end[i], r[i, 6], r[i, 7], r[i, 4] * 0.01, r[i, 3] * 0.01, r[i, 2] * 0.01))
+    print("   life percentiles 50 / 90 / 99 / max: %s us; groups per wave 50 / 90 / 99 / max: %s" % (" / ".join("%.1f" % np.percentile(life, q) for q in (50, 90, 99, 100)), " / ".join("%d" % np.percentile(r[:, 6], q) for q in (50, 90, 99, 100))))
