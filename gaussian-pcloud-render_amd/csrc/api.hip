@@ -8,7 +8,7 @@
 //             depth sort of the P Gaussians                       4 passes x 3 launches, u32 key / u32 id
 //             pair emission in depth order with its own prefix sum  1 launch     -> num_rendered, ON THE DEVICE
 //             tile sort                                           ceil(bit/8) passes x 3 launches, u16|u32 tile / u32 id
-//             tile ranges (search), tile order by list length     2 launches
+//             tile ranges (search), tile order by work estimate   2 launches
 //             render                                              1 launch
 //   backward  work items, render backward, per-Gaussian backward  3 launches
 //

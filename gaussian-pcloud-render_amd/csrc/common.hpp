@@ -146,7 +146,7 @@ struct ImageView {
     uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
-    uint32_t* tile_order; // [T] tiles by descending list length (forward render launch order)
+    uint32_t* tile_order; // [T] tiles by descending work estimate (forward render launch order, binning.hip k_tile_order)
     float* accum;         // [3N] colour accumulated by the forward render, without the background term (only written
                           //      for quadrants that crossed a BWD_CHUNK boundary: the only ones whose backward reads it)
     uint32_t* bwd_items;  // [BWD_MAX_CHUNKS * T] backward work items: tile | chunk << BWD_TILE_BITS, heaviest first

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 python scripts/literal_host_trace.py 240 > $OUT/trace.json 2> $OUT/trace.err
 cat $OUT/trace.json
 tail -3 $OUT/trace.err
-if [ -d scratch_ab/pkg_old ]; then
+if [ -d scratch_ab/pkg_old ]; then   # (an older copy of the Python package put there by hand for an A/B in one lease)
   python scripts/literal_host_trace.py 240 scratch_ab/pkg_old > $OUT/trace_old.json 2> $OUT/trace_old.err
   cat $OUT/trace_old.json; tail -3 $OUT/trace_old.err
   python scripts/literal_host_trace.py 240 > $OUT/trace2.json 2>> $OUT/trace.err
