@@ -150,6 +150,27 @@ static thread_local std::vector<int64_t> t_list_pairs;
 // device->host read-backs the library has issued since it was loaded (one per forward call: the per-view counters)
 static std::atomic<long long> g_d2h_count{0};
 
+// ---- which way the sorts run (common.hpp sort_mode) ------------------------------------------------------------------------------
+static std::atomic<int> g_sort_mode{[] { const char* e = getenv("GSR_SORT_MODE"); const int m = e ? atoi(e) : 0; return m < 0 || m > 2 ? 0 : m; }()};
+static std::atomic<int> g_sort_lb_views{[] { const char* e = getenv("GSR_SORT_LB_VIEWS"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }()};
+static std::atomic<int> g_tickets{[] { const char* e = getenv("GSR_TICKETS"); return e && atoi(e) != 0 ? 1 : 0; }()};
+int block_tickets(int set)
+{
+    if (set >= 0) g_tickets = set != 0;
+    return g_tickets;
+}
+int sort_mode(int set)
+{
+    if (set >= 0 && set <= 2) g_sort_mode = set;
+    return g_sort_mode;
+}
+int lookback_max_views(int set)
+{
+    if (set >= 0) g_sort_lb_views = set;
+    return g_sort_lb_views;
+}
+static bool use_lookback(int V) { const int m = g_sort_mode; return m == 1 || (m == 2 && V <= g_sort_lb_views); }
+
 static int tile_count(const gsr_params* p) { return ((p->W + TILE_X - 1) / TILE_X) * ((p->H + TILE_Y - 1) / TILE_Y); }
 
 static int check_params(const gsr_params* p, int V = 1)
@@ -249,6 +270,9 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
     const int T = tile_count(p);
     const int gridx = (p->W + TILE_X - 1) / TILE_X;
     const bool key16 = tile_keys16(T);
+    // the emission kernel leaves the counters of every view in mapped host memory (and a sort pass that gives up waiting raises its
+    // flag there); cleared before the first kernel that may store into it is enqueued
+    memset(t_land.pinned, 0, (size_t)V * 4 * sizeof(uint64_t));
 
     if (mode == 1) {
         // the first attempt consumed the frame's bookkeeping: clear it again (k_preprocess did it the first time)
@@ -266,16 +290,20 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
             SortJob job{{B.g.dkey[0], B.g.dkey[1]}, {B.g.dval[0], B.g.dval[1]}, B.g.hist, B.g.totals, B.g_stride, nullptr, 0, p->P, V};
             job.blk_minmax = B.g.blk_minmax;
             job.sortctl = B.g.sortctl;
-            // half-size sort blocks while whole-size ones would leave the chip short of workgroups
-            job.small_blocks = div_up(p->P, RS_TILE) * V < 4096;
-            int res = 0;
-            if (int e = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 32, &res)) return e;
+            if (use_lookback(V) && lb_fits(p->P)) {
+                LbJob lj{B.g.lb, lb_pass_words(p->P), B.g.ghist, B.g_stride, B.g.counters, B.g_stride, t_land.mapped};
+                lj.pre_minmax = B.g.pre_minmax;
+                if (int e = launch_depth_sort_lookback(L, job, lj)) return e;
+            } else {
+                // half-size sort blocks while whole-size ones would leave the chip short of workgroups
+                job.small_blocks = div_up(p->P, RS_TILE) * V < 4096;
+                int res = 0;
+                if (int e = launch_radix_sort_pairs(L, job, /*iota_vals=*/true, 32, &res)) return e;
+            }
             // up to 4 passes (B.g.sortctl says how many did something): the ids in depth order are in dval[passes & 1]
         }
     }
-    // the emission kernel leaves the counters of every view in mapped host memory; the event behind it is waited for only
-    // after the rest of the frame has been enqueued
-    memset(t_land.pinned, 0, (size_t)V * 4 * sizeof(uint64_t));
+    // the event behind the emission kernel is waited for only after the rest of the frame has been enqueued.
     // Once the emission is in the stream it WILL store into the landing zone, whatever happens to the launches behind it: an
     // early return must not leave it pending (the next call of this thread clears the zone from the host and would race
     // with those late stores), so every error path below drains the stream first.
@@ -291,17 +319,33 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         }
         if (mode != 2) {
             const int res = sorted_buffer(T);
+            // look-back passes: images of up to LB_MAX_TILES tiles (the histogram over whole keys lives in LDS), arenas of up to
+            // LB_MAX_BLOCKS sort blocks per view; the tile ranges are then prefix sums of the histogram
+            const bool lookback = use_lookback(V) && tile_bits(T) <= 15 && lb_fits(B.b.cap);
             {
                 ProfScope ps("tile_sort", L.stream);
                 SortJob job{{B.b.key[0], B.b.key[1]}, {B.b.val[0], B.b.val[1]}, B.b.hist, B.b.totals, B.b_stride,
                             B.g.counters + CNT_NUM_RENDERED, B.g_stride, B.b.cap, V};
                 int r2 = 0;
-                if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
+                if (lookback) {
+                    LbJob lj{B.b.lb, lb_pass_words(B.b.cap), B.iv.tile_ghist, B.iv_stride, B.g.counters, B.g_stride, t_land.mapped};
+                    lj.tile_count = B.iv.tile_count;
+                    if (int e = launch_tile_sort_lookback(L, job, lj, T, tile_bits(T), &r2, key16)) return e;
+                } else {
+                    if (int e = launch_radix_sort_pairs(L, job, false, tile_bits(T), &r2, key16)) return e;
+                }
             }
             {
                 ProfScope ps("tile_ranges", L.stream);
-                if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
-                if (int e = launch_tile_order(L, B, T)) return e;
+                if (lookback) {
+                    if (int e = launch_ranges_order(L, B, T)) return e;
+                } else {
+                    // (one launch of one workgroup per view doing both was measured: 47 us instead of 7 + 11 for a single view --
+                    // 8 160 binary searches are ~100 000 scattered line requests, and ONE CU's address unit passes about one line
+                    // per cycle; the search wants its 32 workgroups.  gpurun_out/r6e, profiles/r06_lookback_sort.txt)
+                    if (int e = launch_tile_ranges(L, B, B.b.key[res], T, key16)) return e;
+                    if (int e = launch_tile_order(L, B, T)) return e;
+                }
             }
             {
                 ProfScope ps("render_forward", L.stream);
@@ -338,6 +382,108 @@ static int forward_impl(const gsr_params* p, int V, void* geom, size_t geom_byte
         fail(GSR_RETRY, "[gsr] binning arena holds %lld pairs per view, the frame needs more (num_rendered is enough; gsr_last_list_pairs is exact): repeat with resume = 1",
              (long long)B.b.cap);
         return GSR_RETRY;
+    }
+    return GSR_OK;
+}
+
+// The look-back sorts on their own buffers: (1) tile-sort shaped -- 12-bit keys with many ties, explicit values, the element
+// count on the device, pairs per tile checked against a host histogram; (2) depth-sort shaped -- 32-bit keys that differ in 17
+// bits above a base (three passes run, the fourth leaves), values = indices, key extremes handed over like k_preprocess does.
+struct DevBuffers {   // selftest allocations, freed on every way out
+    std::vector<void*> all;
+    ~DevBuffers() { for (void* p : all) (void)hipFree(p); }
+    template <typename T_> T_* get(size_t count)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, count * sizeof(T_) + 16) != hipSuccess) return nullptr;
+        all.push_back(p);
+        return (T_*)p;
+    }
+};
+static int selftest_lookback(hipStream_t s, const std::vector<uint32_t>& hk, const std::vector<uint32_t>& order)
+{
+    const int64_t n = (int64_t)hk.size();
+    const int T = 3001;
+    const size_t pw = lb_pass_words(n);
+    DevBuffers dev;
+    uint32_t* k0 = dev.get<uint32_t>(n); uint32_t* k1 = dev.get<uint32_t>(n);
+    uint32_t* v0 = dev.get<uint32_t>(n); uint32_t* v1 = dev.get<uint32_t>(n);
+    uint32_t* lbw = dev.get<uint32_t>(4 * pw); uint32_t* ghist = dev.get<uint32_t>(4 * RADIX);
+    uint32_t* tcount = dev.get<uint32_t>(T); uint64_t* cnt = dev.get<uint64_t>(8);
+    uint32_t* mm = dev.get<uint32_t>(2 * (size_t)div_up(n, PRE_THREADS)); uint32_t* ctl = dev.get<uint32_t>(4);
+    if (!k0 || !k1 || !v0 || !v1 || !lbw || !ghist || !tcount || !cnt || !mm || !ctl) return fail(GSR_ERR_HIP, "[gsr] selftest: hipMalloc failed");
+    const Launch L{s, 1};
+    std::vector<uint32_t> iota(n), gk(n), gv(n);
+    for (int64_t i = 0; i < n; i++) iota[i] = (uint32_t)i;
+    // (1)
+    {
+        uint64_t hc[8] = {(uint64_t)n, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyAsync(k0, hk.data(), n * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(v0, iota.data(), n * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(cnt, hc, sizeof(hc), hipMemcpyHostToDevice, s);
+        (void)hipMemsetAsync(ghist, 0, 4 * RADIX * 4, s);
+        (void)hipMemsetAsync(tcount, 0, T * 4, s);
+        (void)hipMemsetAsync(lbw, 0xFF, 4 * pw * 4, s);   // the histogram kernel has to clear it
+        const SortJob job{{k0, k1}, {v0, v1}, nullptr, nullptr, 0, cnt + CNT_NUM_RENDERED, 0, n, 1};
+        LbJob lj{lbw, pw, ghist, 0, cnt, 0, nullptr};
+        lj.tile_count = tcount;
+        int res = 0;
+        if (int rc = launch_tile_sort_lookback(L, job, lj, T, 12, &res, false)) return rc;
+        uint32_t* key[2] = {k0, k1};
+        uint32_t* val[2] = {v0, v1};
+        std::vector<uint32_t> tc(T), want(T, 0u);
+        (void)hipMemcpyAsync(gk.data(), key[res], n * 4, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(gv.data(), val[res], n * 4, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(tc.data(), tcount, T * 4, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: look-back tile sort failed: %s", hipGetErrorString(hipGetLastError()));
+        if (hc[CNT_STALL]) return fail(GSR_ERR_HIP, "[gsr] selftest: a look-back pass gave up waiting");
+        for (int64_t i = 0; i < n; i++) {
+            want[hk[i]]++;
+            if (gv[i] != order[i] || gk[i] != hk[order[i]]) return fail(GSR_ERR_HIP, "[gsr] selftest: look-back tile sort differs from std::stable_sort at %lld", (long long)i);
+        }
+        for (int t = 0; t < T; t++)
+            if (tc[t] != want[t]) return fail(GSR_ERR_HIP, "[gsr] selftest: pairs per tile wrong at tile %d", t);
+    }
+    // (2)
+    {
+        std::vector<uint32_t> dk(n), dord(n);
+        uint32_t x = 99u, lo = 0xFFFFFFFFu, hi = 0u;
+        for (int64_t i = 0; i < n; i++) {
+            x = x * 1664525u + 1013904223u;
+            dk[i] = (i % 11 == 3) ? CULLED_KEY : 0x3FFF8000u + (x >> 9) % 70000u;   // straddles the binade boundary at 2.0
+            if (dk[i] != CULLED_KEY) { lo = dk[i] < lo ? dk[i] : lo; hi = dk[i] > hi ? dk[i] : hi; }
+            dord[i] = (uint32_t)i;
+        }
+        const uint32_t base = lo & ~255u;
+        // three passes compare the low 24 bits of (key - base): a culled key lands wherever those bits put it (its place is immaterial)
+        std::stable_sort(dord.begin(), dord.end(), [&](uint32_t a, uint32_t b) { return ((dk[a] - base) & 0xFFFFFFu) < ((dk[b] - base) & 0xFFFFFFu); });
+        const int n_pre = (int)div_up(n, PRE_THREADS);
+        std::vector<uint32_t> hmm(2 * (size_t)n_pre);
+        for (int b = 0; b < n_pre; b++) { hmm[b] = b == 7 ? lo : 0xFFFFFFFFu; hmm[n_pre + b] = b == n_pre - 1 ? hi : 0u; }
+        uint64_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyAsync(k0, dk.data(), n * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(mm, hmm.data(), hmm.size() * 4, hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(cnt, hc, sizeof(hc), hipMemcpyHostToDevice, s);
+        (void)hipMemsetAsync(ghist, 0, 4 * RADIX * 4, s);
+        (void)hipMemsetAsync(lbw, 0xFF, 4 * pw * 4, s);
+        SortJob job{{k0, k1}, {v0, v1}, nullptr, nullptr, 0, nullptr, 0, n, 1};
+        job.sortctl = ctl;
+        LbJob lj{lbw, pw, ghist, 0, cnt, 0, nullptr};
+        lj.pre_minmax = mm;
+        if (int rc = launch_depth_sort_lookback(L, job, lj)) return rc;
+        uint32_t hctl[4];
+        (void)hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: look-back depth sort failed: %s", hipGetErrorString(hipGetLastError()));
+        const uint32_t passes = depth_sort_passes(hctl[SORTCTL_BITS]);
+        if (hctl[SORTCTL_BASE] != base || passes != 3u) return fail(GSR_ERR_HIP, "[gsr] selftest: depth-sort control words wrong (base %08x, %u passes)", hctl[SORTCTL_BASE], passes);
+        uint32_t* val[2] = {v0, v1};
+        (void)hipMemcpyAsync(gv.data(), val[passes & 1], n * 4, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(GSR_ERR_HIP, "[gsr] selftest: copy failed");
+        if (hc[CNT_STALL]) return fail(GSR_ERR_HIP, "[gsr] selftest: a look-back pass gave up waiting");
+        for (int64_t i = 0; i < n; i++)
+            if (gv[i] != dord[i]) return fail(GSR_ERR_HIP, "[gsr] selftest: look-back depth sort differs from std::stable_sort at %lld", (long long)i);
     }
     return GSR_OK;
 }
@@ -629,7 +775,7 @@ int gsr_selftest(gsr_stream_t stream)
     if (rc != 0) return rc;
     for (int64_t i = 0; i < n; i++)
         if (gv[i] != order[i] || gk[i] != hk[order[i]]) return fail(GSR_ERR_HIP, "[gsr] selftest: radix sort differs from std::stable_sort at %lld", (long long)i);
-    return GSR_OK;
+    return selftest_lookback(s, hk, order);
 }
 
 int gsr_clock_probe_launch(void* dst16, int iters, gsr_stream_t stream)
@@ -687,6 +833,11 @@ __attribute__((visibility("default"))) int gsr_debug_dup_times(unsigned long lon
 
 long long gsr_d2h_count(void) { return gsr::g_d2h_count.load(); }
 int gsr_set_forward_half_views(int views) { return gsr::forward_half_views(views); }
+int gsr_set_sort_mode(int mode, int lookback_views)
+{
+    if (lookback_views >= 0) (void)gsr::lookback_max_views(lookback_views);
+    return gsr::sort_mode(mode);
+}
 int gsr_set_backward_moments(int mode) { return gsr::backward_subquadrant_moments(mode); }
 
 int gsr_last_list_pairs(int64_t* out, int V)

@@ -71,6 +71,7 @@ struct DupArgs {
     size_t b_stride;
     int64_t cap;
     uint64_t* host_land;             // [V][4] host memory mapped into the device: num_rendered, trap flag, stall flag, - (api.hip)
+    int tickets;                     // common.hpp block_tickets
 };
 
 template <typename KeyT>
@@ -89,12 +90,12 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     const uint32_t view = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t* status = at_view(a.dup_status, a.g_stride, view);
-    // Which DUP_BLOCK Gaussians this workgroup takes is decided by a ticket drawn when it STARTS: a workgroup with a lower number
-    // has started earlier, so the look-back below only ever waits for workgroups that are already running or done, whatever
-    // order the hardware dispatches blockIdx in (HIP promises none).  The ticket word follows the status words.
+    // Which DUP_BLOCK Gaussians this workgroup takes: its blockIdx, or (a.tickets) a ticket drawn when it STARTS -- the look-back
+    // below only ever waits for lower-numbered workgroups (common.hpp block_tickets: why that ends, and what the tickets cost).
+    // The ticket word follows the status words.
     const uint32_t nblk = gridDim.x;
     DUP_T(t0);
-    if (threadIdx.x == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long*)&status[nblk], 1ull);
+    if (threadIdx.x == 0) s_ticket = a.tickets ? (uint32_t)atomicAdd((unsigned long long*)&status[DUP_COPIES * nblk], 1ull) : blockIdx.x;
     __syncthreads();
     DUP_T(t1);
     DUP_ADD(0, t1 - t0);
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     // exceeds the int the reference keeps num_rendered in, which the host reports as an error before anything uses the lists.
     const uint64_t sat = 0xFFFFFFFEull;
     const uint64_t word = ((block_total < sat ? block_total : sat) + 1ull) | ((block_ref < 0xFFFFFFFFull ? block_ref : 0xFFFFFFFFull) << 32);
-    if (threadIdx.x == 0) agent_store(&status[blk], word);
+    // Published DUP_COPIES times: what workgroups of one launch tell each other goes around the L2s (they are not coherent across
+    // XCDs), and accesses to ONE line of that kind complete at about one per 50 ns -- the first status lines are read by every
+    // workgroup behind them (782 at 800 K Gaussians: 40 us, the whole kernel).  A reader takes copy (its number mod DUP_COPIES).
+    if (threadIdx.x < DUP_COPIES) agent_store(&status[threadIdx.x * nblk + blk], word);
     DUP_T(t2);
     DUP_ADD(1, t2 - t1);
     // look-back: every preceding workgroup's count (published as count + 1; 0 = not yet).  They were dispatched before
@@ -177,18 +181,19 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     // LB words per thread are requested back to back (one round trip to the fabric instead of LB); a word that has not been
     // published yet is polled afterwards.
     constexpr uint32_t LB = 4;
+    const uint64_t* mine = status + (size_t)(blk % DUP_COPIES) * nblk;
     for (uint32_t b0 = threadIdx.x; b0 < blk; b0 += DUP_THREADS * LB) {
         uint64_t v[LB];
 #pragma unroll
         for (uint32_t k = 0; k < LB; k++) {
             const uint32_t b = b0 + k * DUP_THREADS;
-            v[k] = b < blk ? agent_load(&status[b]) : 1ull;
+            v[k] = b < blk ? agent_load(&mine[b]) : 1ull;
         }
 #pragma unroll
         for (uint32_t k = 0; k < LB; k++) {
             uint32_t spins = 0;
             while ((uint32_t)v[k] == 0u) {
-                v[k] = agent_load(&status[b0 + k * DUP_THREADS]);
+                v[k] = agent_load(&mine[b0 + k * DUP_THREADS]);
                 if ((uint32_t)v[k] == 0u && ++spins > (1u << 24)) {   // seconds: something is badly wrong; report instead of hanging the GPU
                     at_view(a.counters, a.g_stride, view)[CNT_STALL] = 1;
                     a.host_land[4 * view + CNT_STALL] = 1;
@@ -336,6 +341,7 @@ int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key
     a.b_stride = B.b_stride;
     a.cap = B.b.key[0] ? B.b.cap : 0;
     a.host_land = host_land;
+    a.tickets = block_tickets(-1);
     const dim3 grid((unsigned)div_up(P, DUP_BLOCK), B.V);
     if (key16)
         hipLaunchKernelGGL(k_duplicate<uint16_t>, grid, dim3(DUP_THREADS), 0, L.stream, a);
@@ -499,10 +505,111 @@ __global__ __launch_bounds__(1024) void k_tile_order(int T, const uint2* __restr
     }
 }
 
+// ---- ranges + launch order in one workgroup per view, from the pairs-per-tile counts (look-back tile sort) ------------------
+// The single-read histogram kernel of the tile sort (sort.hip k_tile_hist) leaves the number of pairs of every tile: the ranges
+// are their exclusive prefix sums (what the reference finds by comparing neighbouring sorted keys, CR/rasterizer_impl.cu:116-138,
+// and the search kernel above by 12 dependent loads per tile), and the launch order needs nothing else either: one launch of one
+// workgroup per view instead of two, off the sorted keys altogether.  A thread owns ceil(T / 1024) consecutive tiles.
+__global__ __launch_bounds__(1024) void k_ranges_order(int T, const uint32_t* tile_count, uint2* __restrict__ ranges,
+                                                       uint32_t* __restrict__ tile_order, size_t iv_stride, float knee, float expo)
+{
+    tile_count = at_view(tile_count, iv_stride, blockIdx.x);
+    ranges = at_view(ranges, iv_stride, blockIdx.x);
+    tile_order = at_view(tile_order, iv_stride, blockIdx.x);
+    // the counts are staged in LDS with ONE round of coalesced loads (they were accumulated by memory-side atomics: every global
+    // read of them is a round trip to the fabric, and the three walks below made 3 x ceil(T / 1024) dependent ones: 19 us)
+    extern __shared__ uint32_t tc_lds[];
+    for (int t = threadIdx.x; t < T; t += 1024) tc_lds[t] = tile_count[t];
+    __syncthreads();
+    tile_count = tc_lds;
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t cnt[ORD_BUCKETS];
+    __shared__ uint32_t cur[ORD_BUCKETS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (tid < ORD_BUCKETS) cnt[tid] = 0;
+    const int per = (T + 1023) / 1024;
+    const int t0 = (int)tid * per;
+    uint32_t sum = 0;
+    for (int i = 0; i < per; i++)
+        if (t0 + i < T) sum += tile_count[t0 + i];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += x;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (uint32_t i = 0; i < w; i++) base += wsum[i];
+    // ranges + bucket counts; the thousands of empty tiles share one bucket: one LDS atomic per wave for them
+    for (int i = 0; i < per; i++) {
+        const int t = t0 + i;
+        const bool ok = t < T;
+        const uint32_t c = ok ? tile_count[t] : 0u;
+        if (ok) ranges[t] = c ? make_uint2(base, base + c) : make_uint2(0u, 0u);
+        base += c;
+        const uint32_t b = ok ? work_bucket(work_estimate(c, knee, expo)) : 0u;
+        const bool empty = ok && b == ORD_BUCKETS - 1;
+        const uint64_t em = __ballot(empty);
+        if (empty) { if ((em & lt_mask) == 0) atomicAdd(&cnt[b], (uint32_t)__popcll(em)); }
+        else if (ok) atomicAdd(&cnt[b], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of 128 counts by one wave, two per lane
+        const uint32_t a0 = cnt[2 * lane], a1 = cnt[2 * lane + 1];
+        uint32_t in2 = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(in2, d, 64);
+            if (lane >= (uint32_t)d) in2 += x;
+        }
+        cur[2 * lane] = in2 - a0 - a1;
+        cur[2 * lane + 1] = in2 - a1;
+    }
+    __syncthreads();
+    for (int i = 0; i < per; i++) {
+        const int t = t0 + i;
+        const bool ok = t < T;
+        const uint32_t c = ok ? tile_count[t] : 0u;
+        const uint32_t b = ok ? work_bucket(work_estimate(c, knee, expo)) : 0u;
+        const bool empty = ok && b == ORD_BUCKETS - 1;
+        const uint64_t em = __ballot(empty);
+        uint32_t slot = 0, basev = 0;
+        const int leader = em ? (int)__builtin_ctzll(em) : 0;
+        if (empty && (int)lane == leader) basev = atomicAdd(&cur[b], (uint32_t)__popcll(em));
+        basev = __shfl(basev, leader, 64);
+        if (empty) slot = basev + (uint32_t)__popcll(em & lt_mask);
+        else if (ok) slot = atomicAdd(&cur[b], 1u);
+        if (ok) tile_order[slot] = (uint32_t)t;
+    }
+}
+
+static void order_params(float& knee, float& expo)
+{
+    static const float k = [] { const char* e = getenv("GSR_ORDER_KNEE"); return e ? (float)atof(e) : 2048.f; }();
+    static const float x = [] { const char* e = getenv("GSR_ORDER_EXP"); return e ? (float)atof(e) : 0.3f; }();
+    knee = k;
+    expo = x;
+}
+
+int launch_ranges_order(const Launch& L, const Batch& B, int T)
+{
+    float knee, expo;
+    order_params(knee, expo);
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ranges_order), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   4 * LB_MAX_TILES) == hipSuccess;
+    (void)lds_ok;
+    hipLaunchKernelGGL(k_ranges_order, dim3(B.V), dim3(1024), (size_t)T * 4, L.stream, T, B.iv.tile_count, B.iv.ranges, B.iv.tile_order, B.iv_stride,
+                       knee, expo);
+    return check_launch(L, "ranges_order");
+}
+
 int launch_tile_order(const Launch& L, const Batch& B, int T)
 {
-    static const float knee = [] { const char* e = getenv("GSR_ORDER_KNEE"); return e ? (float)atof(e) : 2048.f; }();
-    static const float expo = [] { const char* e = getenv("GSR_ORDER_EXP"); return e ? (float)atof(e) : 0.3f; }();
+    float knee, expo;
+    order_params(knee, expo);
     hipLaunchKernelGGL(k_tile_order, dim3(B.V), dim3(1024), 0, L.stream, T, B.iv.ranges, B.iv.tile_order, B.iv_stride, knee, expo);
     return check_launch(L, "tile_order");
 }

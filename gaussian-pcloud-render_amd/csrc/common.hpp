@@ -18,6 +18,12 @@
 
 #include "../../include/gsr.h"
 
+// One target: the kernels use gfx950 instructions without a second path (v_permlane32_swap, bitop3, fp32 MFMA shapes, the
+// 160-KB LDS); another --offload-arch stops here instead of failing somewhere inside an assembler line.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgsr_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace gsr {
 
 constexpr int TILE_X = 16;  // reference CR/config.h:16-17 -- defines keys / ranges, must not change
@@ -43,12 +49,40 @@ constexpr int RS_ITEMS_SMALL = 8;
 constexpr int RS_TILE_SMALL = RS_THREADS * RS_ITEMS_SMALL;
 inline int sort_hist_stride(int64_t n, int tile = RS_TILE) { return (int)(((n + tile - 1) / tile + 15) / 16 * 16); }
 
+// ---- single-read histogram + look-back passes ("onesweep", sort.hip) ---------------------------------------------------------
+// One kernel reads the keys once and counts the digits of EVERY pass (global digit totals do not depend on the order of the
+// keys); a pass is then ONE scatter launch whose workgroups find their per-digit offsets by looking back at the counts the
+// preceding workgroups of the same launch have published.  Bookkeeping of one pass (u32 words, cleared by the histogram kernel):
+//   [LB_HDR]            word 0 = the ticket counter that numbers the workgroups in the order they START
+//   [nblk][nd]          count + 1 of digit d in block b        (0 = not published yet)
+//   [ngrp][nd]          count + 1 of digit d in the LB_GROUP blocks of group g, published by the group's last block
+// nd = digits of the pass (rows are compact).  A block reads the sums of the groups before its own and the counts of the
+// earlier blocks of its own group: at most ngrp + LB_GROUP - 1 rows, every one of them final when it is first non-zero -- no
+// chain of dependent hops (a hop to another XCD's data costs about a microsecond on this part).
+constexpr int LB_HDR = 64;
+constexpr int LB_GROUP = 32;
+constexpr int64_t LB_MAX_BLOCKS = 4096;   // larger problems run the three-launch passes (a block would read > 160 rows)
+inline int64_t lb_blocks(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+inline bool lb_fits(int64_t n) { return lb_blocks(n) <= LB_MAX_BLOCKS; }
+inline size_t lb_pass_words(int64_t n)    // arena words of one pass' bookkeeping for up to n keys (non-decreasing in n: arena sizes must be)
+{
+    const int64_t nblk = lb_blocks(n) < LB_MAX_BLOCKS ? lb_blocks(n) : LB_MAX_BLOCKS;
+    return (size_t)LB_HDR + (size_t)(nblk + (nblk + LB_GROUP - 1) / LB_GROUP) * RADIX;
+}
+constexpr int LB_TILE_PASSES = 2;         // tile sort: images of up to LB_MAX_TILES tiles (two passes, full-key histogram in LDS)
+constexpr int LB_MAX_TILES = 32768;
+constexpr int PRE_THREADS = 256;          // Gaussians per k_preprocess workgroup (one depth-key range record each)
+
 constexpr int DUP_THREADS = 256;  // Gaussians per pair-emission workgroup (binning.hip)
 #ifndef GSR_DUP_G
 #define GSR_DUP_G 4
 #endif
 constexpr int DUP_G = GSR_DUP_G;                    // Gaussians per thread of the pair emission
-constexpr int DUP_BLOCK = DUP_THREADS * DUP_G;     // Gaussians per emission workgroup (one ticket, one look-back)
+constexpr int DUP_BLOCK = DUP_THREADS * DUP_G;     // Gaussians per emission workgroup (one look-back)
+#ifndef GSR_DUP_COPIES
+#define GSR_DUP_COPIES 8
+#endif
+constexpr int DUP_COPIES = GSR_DUP_COPIES;         // copies of the emission's status words (binning.hip: hot lines)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -101,10 +135,13 @@ struct GeomView {
     uint32_t* hist;           // [RADIX * nblk(P)] per-workgroup digit counts (depth sort)
     uint32_t* totals;         // [RADIX]
     uint32_t* blk_minmax;     // [2 * nblk(P)] smallest / largest depth key of a visible Gaussian per sort block (pass 0's histogram)
+    uint32_t* pre_minmax;     // [2 * ceil(P / PRE_THREADS)] the same per k_preprocess workgroup (single-read histogram kernel)
+    uint32_t* lb;             // [4 * lb_pass_words(P)] look-back bookkeeping of the four depth-sort passes
     uint32_t* sortctl;        // [4] SORTCTL_*: which key bits the depth sort really has to look at this frame (sort.hip)
-    uint64_t* dup_status;     // [ceil(P / DUP_THREADS) + 1] pair count + 1 of each emission workgroup, then the ticket counter
+    uint64_t* dup_status;     // [DUP_COPIES][ceil(P / DUP_BLOCK)] pair count + 1 of each emission workgroup, then the ticket counter
+    uint32_t* ghist;          // [4 * RADIX] digit totals of the depth keys, all passes (accumulated by k_depth_hist)
     uint64_t* counters;       // [8]  (CNT_*; the trap word is cleared by the host only for prefiltered calls)
-    char* zero_begin;         // dup_status: cleared by k_preprocess at the start of every frame
+    char* zero_begin;         // dup_status, ghist: cleared by k_preprocess at the start of every frame
     size_t zero_bytes;
     size_t bytes;
 };
@@ -133,6 +170,7 @@ struct BinView {
     uint32_t* val[2];  // [cap] Gaussian ids, ping-pong
     uint32_t* hist;    // [RADIX * nblk(cap)]
     uint32_t* totals;  // [RADIX]
+    uint32_t* lb;      // [LB_TILE_PASSES * lb_pass_words(cap)] look-back bookkeeping of the tile sort's passes
     float4* ckpt;      // [((cap >> BWD_CHUNK_SHIFT_MIN) + 2) * 256] forward state (T, C.rgb) per pixel of a tile at list position
                        // range.x + k * chunk, slot (range.x >> chunk shift) + k  (unique: lists do not overlap)
     int64_t cap;
@@ -143,6 +181,8 @@ struct ImageView {
     uint32_t* tile_need;  // [T] entries walked by the forward render  } cleared by k_preprocess at the start of
     uint32_t* bwd_count;  // [16] [0] number of backward items         } every frame
                           //      words BWD_QUEUE_WORD .. + 7: the render backward's work-unit counters of the view, one per XCD (zeroed by k_bwd_items)
+    uint32_t* tile_count; // [T] pairs per tile                        } (accumulated by k_tile_hist: ranges = their prefix sums)
+    uint32_t* tile_ghist; // [LB_TILE_PASSES * RADIX] digit totals of the tile keys, both passes
     uint2* ranges;        // [T] (first, one past last) list position per tile; (0, 0) for empty tiles
     float* final_T;       // [N]
     uint32_t* n_contrib;  // [N]
@@ -178,9 +218,12 @@ inline GeomView geom_view(void* base, int P)
     carve(cur, g.hist, RADIX * nblk);
     carve(cur, g.totals, (size_t)RADIX);
     carve(cur, g.blk_minmax, 2 * nblk);
+    carve(cur, g.pre_minmax, 2 * (size_t)div_up((int64_t)p, PRE_THREADS));
+    carve(cur, g.lb, 4 * lb_pass_words((int64_t)p));
     carve(cur, g.sortctl, (size_t)4);
     g.zero_begin = cur;
-    carve(cur, g.dup_status, (size_t)div_up((int64_t)p, DUP_THREADS) + 1);   // + the ticket counter
+    carve(cur, g.dup_status, (size_t)DUP_COPIES * (size_t)div_up((int64_t)p, DUP_BLOCK) + 1);   // + the ticket counter
+    carve(cur, g.ghist, (size_t)4 * RADIX);
     g.zero_bytes = (size_t)(cur - g.zero_begin);
     carve(cur, g.counters, (size_t)8);
     g.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
@@ -199,6 +242,7 @@ inline BinView bin_view(void* base, int64_t cap)
     carve(cur, b.val[1], r);
     carve(cur, b.hist, RADIX * nblk);
     carve(cur, b.totals, (size_t)RADIX);
+    carve(cur, b.lb, LB_TILE_PASSES * lb_pass_words((int64_t)r));
     carve(cur, b.ckpt, ((r >> BWD_CHUNK_SHIFT_MIN) + 2) * 256);
     b.cap = (int64_t)r;
     b.bytes = (size_t)(cur - reinterpret_cast<char*>(base));
@@ -226,6 +270,8 @@ inline ImageView image_view(void* base, int W, int H)
     v.zero_begin = cur;
     carve(cur, v.tile_need, T ? T : 1);
     carve(cur, v.bwd_count, (size_t)16);
+    carve(cur, v.tile_count, T ? T : 1);
+    carve(cur, v.tile_ghist, (size_t)LB_TILE_PASSES * RADIX);
     v.zero_bytes = (size_t)(cur - v.zero_begin);
     carve(cur, v.ranges, T ? T : 1);
     carve(cur, v.final_T, N ? N : 1);
@@ -304,11 +350,39 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;   // depth key of a Gaussian that e
 // number of depth-sort passes a frame with SORTCTL_BITS = bits executes; ids in depth order end up in dval[passes & 1]
 __host__ __device__ inline uint32_t depth_sort_passes(uint32_t bits) { return (bits + RADIX_BITS - 1) / RADIX_BITS; }
 int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals, int end_bit, int* result_buffer, bool key16 = false);
+// The same sorts as single-read histogram + look-back passes (sort.hip; bit-identical results, fewer launches).
+struct LbJob {
+    uint32_t* lb;                 // view 0's look-back bookkeeping (in the arena of the keys: job.stride apart), pass after pass
+    size_t pass_words;
+    uint32_t* ghist;              // view 0's digit totals [passes][RADIX], cleared at the start of the frame
+    size_t ghist_stride;
+    uint64_t* counters;           // view 0's CNT_* words
+    size_t cnt_stride;
+    uint64_t* host_land;          // mapped host landing zone or NULL
+    const uint32_t* pre_minmax = nullptr;   // depth sort: k_preprocess' per-workgroup key extremes
+    uint32_t* tile_count = nullptr;         // tile sort: [T] pairs per tile, cleared at the start of the frame
+};
+int launch_depth_sort_lookback(const Launch& L, const SortJob& job, const LbJob& lj);
+int launch_tile_sort_lookback(const Launch& L, const SortJob& job, const LbJob& lj, int T, int end_bit, int* result_buffer, bool key16);
+// which way the sorts of a submission run: 0 three launches per pass, 1 look-back passes, 2 (default) look-back for submissions of up
+// to lookback_max_views() views.  set < 0 only queries.  (api.hip; GSR_SORT_MODE / GSR_SORT_LB_VIEWS in the environment)
+// How the kernels whose workgroups wait for lower-numbered workgroups of the same launch (pair emission, look-back scatter) number
+// themselves.  0 (default): by blockIdx.  The hardware hands the workgroups of a launch to each XCD in increasing order (workgroup i
+// goes to XCD i mod 8, each XCD takes its share in order), so the lowest-numbered unfinished workgroup is always resident or next in
+// line on its XCD, it waits for nothing that is unfinished, and by induction every wait ends; a lower-numbered workgroup that is not
+// yet resident only delays its waiters until a slot frees up.  1 (GSR_TICKETS=1): by a ticket drawn with an atomic when the workgroup
+// starts -- independent of any dispatch order, but every workgroup of the launch then hits ONE address, and same-address atomics from
+// eight XCDs complete at about one per 70 ns: 1 800 scatter workgroups spent 180 us queueing for tickets in a pass that takes 20
+// (gpurun_out/r6b), the emission's 782 workgroups 50 us.  Every wait is bounded either way (CNT_STALL).
+int block_tickets(int set);
+int sort_mode(int set);
+int lookback_max_views(int set);
 inline bool tile_keys16(int T) { return T <= 65536; }
 // binning.hip
 int launch_duplicate(const Launch& L, int P, const Batch& B, int gridx, bool key16, uint64_t* host_land);
 int launch_tile_ranges(const Launch& L, const Batch& B, const uint32_t* sorted_keys, int T, bool key16);
 int launch_tile_order(const Launch& L, const Batch& B, int T);
+int launch_ranges_order(const Launch& L, const Batch& B, int T);   // both from iv.tile_count (look-back tile sort), one launch
 int launch_bwd_items(const Launch& L, const Batch& B, int T, int P);
 // render_fwd.hip / render_bwd.hip
 // point_list: view 0's sorted ids (binning arena); with_ckpt: record the chunk-boundary state for the backward pass

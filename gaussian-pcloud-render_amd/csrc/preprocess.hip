@@ -84,6 +84,8 @@ struct PreArgs {
     uint32_t* tiles_touched;
     uint8_t* clamped;
     uint32_t* dkey;
+    uint32_t* pre_minmax;                 // [2][n_pre] per view: smallest / largest depth key of a visible Gaussian per workgroup
+    int n_pre;
     float* grad_rec;
     uint64_t* counters;
     char* g_zero;                         // per-frame cleared regions of the geometry / image arenas
@@ -97,6 +99,7 @@ struct PreArgs {
 // reused for every view of the batch -- re-reading them per view pulled the 156-B-stride SH rows from HBM five times over)
 // (135 registers at degree 1 = three waves per SIMD; forcing four -- amdgpu_waves_per_eu(4, 4), 128 registers -- spills: 0.029 ->
 // 0.031 ms per view at 12 views per call, 0.067 -> 0.187 at one)
+constexpr int MAX_VIEWS_PER_THREAD = 256;   // (= api.hip MAX_VIEWS)
 template <int DEG>
 __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 {
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
     // covariance, opacity, precomputed colour) are read and prepared ONCE, only the per-view part is repeated, so a batch of V
     // views reads the cloud once instead of V times.
     const int v_first = blockIdx.y * a.vpt, v_last = v_first + a.vpt < a.V ? v_first + a.vpt : a.V;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx_raw = blockIdx.x * 256 + threadIdx.x;
     // this frame's bookkeeping that later kernels accumulate into (prefix-sum status words; consumed-entry counts, backward
     // item count) is cleared here, so a frame needs no memset launches
     {
@@ -118,8 +121,12 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
             zero_region(a.iv_zero + a.iv_stride * vw, a.iv_zero_bytes, gtid, nthr);
         }
     }
-    if (idx >= a.P) return;
+    // Threads past the end of the cloud stay (the workgroup meets at a barrier below): they recompute the last Gaussian and
+    // store nothing.
+    const bool valid = idx_raw < a.P;
+    const int idx = valid ? idx_raw : a.P - 1;
     __shared__ float4 xpose[4][256];   // per wave: 64 Splat lines on their way to coalesced stores
+    __shared__ uint32_t s_mm[MAX_VIEWS_PER_THREAD][4][2];   // per view of this thread and wave: depth-key extremes
 
     const V3 p_orig = v3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     float cov6[6];
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
 
         const V3 p_view = xform_point_4x3(p_orig, view);
         if (p_view.z <= 0.2f) {
-            if (a.prefiltered) at_view(a.counters, a.g_stride, vw)[CNT_TRAP] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
+            if (a.prefiltered && valid) at_view(a.counters, a.g_stride, vw)[CNT_TRAP] = 1;  // reference: printf + __trap() (CR/auxiliary.h:156-160)
         } else {
             const float hx = ((proj[0] * p_orig.x + proj[4] * p_orig.y) + proj[8] * p_orig.z) + proj[12];
             const float hy = ((proj[1] * p_orig.x + proj[5] * p_orig.y) + proj[9] * p_orig.z) + proj[13];
@@ -220,9 +227,23 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
             }
         }
 
-        a.radii[(size_t)vw * a.P + idx] = radius_out;
-        at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
-        at_view(a.dkey, a.g_stride, vw)[idx] = key;
+        if (valid) {
+            a.radii[(size_t)vw * a.P + idx] = radius_out;
+            at_view(a.tiles_touched, a.g_stride, vw)[idx] = tiles;
+            at_view(a.dkey, a.g_stride, vw)[idx] = key;
+        }
+        {
+            // smallest / largest key of a Gaussian that emits pairs, per wave (the depth sort's histogram kernel reduces the
+            // workgroups' records to the key bits the frame's sort has to look at, sort.hip)
+            uint32_t kmin = (valid && key != CULLED_KEY) ? key : 0xFFFFFFFFu, kmax = (valid && key != CULLED_KEY) ? key : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t x = __shfl_xor(kmin, d, 64), y = __shfl_xor(kmax, d, 64);
+                kmin = x < kmin ? x : kmin;
+                kmax = y > kmax ? y : kmax;
+            }
+            if ((threadIdx.x & 63) == 0) { s_mm[vw - v_first][threadIdx.x >> 6][0] = kmin; s_mm[vw - v_first][threadIdx.x >> 6][1] = kmax; }
+        }
         // q3: what the pair emission needs per Gaussian (tile rectangle, tile count), so that it gathers ONE line per
         // Gaussian; the whole 64-B line is written here
         // what the emission needs (binning.hip emit_info): (first tile, last tile + 1, pairs emitted, pairs of the reference's
@@ -231,7 +252,7 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                                                     __uint_as_float(tiles | SPANS_FLAG))
                                       : make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(etiles),
                                                     __uint_as_float(tiles));
-        const int wave_first = idx - (int)(threadIdx.x & 63);
+        const int wave_first = idx_raw - (int)(threadIdx.x & 63);
         const bool full_wave = wave_first + 64 <= a.P;   // wave-uniform
         if (full_wave) {
             // The wave's 64 lines are 4 KB in a row.  A lane storing its own line issues four stores whose lanes are 64 B apart
@@ -245,14 +266,14 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
             const float4 t0 = rd[0], t1 = rd[64], t2 = rd[128], t3 = rd[192];
             out[0] = t0; out[64] = t1; out[128] = t2; out[192] = t3;
             __builtin_amdgcn_wave_barrier();
-        } else {
+        } else if (valid) {
             Splat* sp = at_view(a.splat, a.g_stride, vw) + idx;
             sp->q0 = s.q0;
             sp->q1 = s.q1;
             sp->q2 = s.q2;
             sp->q3 = q3;
         }
-        if (a.need_backward) {
+        if (a.need_backward && valid) {
             at_view(a.clamped, a.g_stride, vw)[idx] = (uint8_t)cmask;
             // the render backward accumulates into this Gaussian's 64-B record: cleared here, alongside the Splat line
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,6 +287,15 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a)
                 rec[0] = z; rec[1] = z; rec[2] = z; rec[3] = z;
             }
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < v_last - v_first) {
+        const uint32_t* m = &s_mm[threadIdx.x][0][0];
+        const uint32_t lo01 = m[0] < m[2] ? m[0] : m[2], lo23 = m[4] < m[6] ? m[4] : m[6];
+        const uint32_t hi01 = m[1] > m[3] ? m[1] : m[3], hi23 = m[5] > m[7] ? m[5] : m[7];
+        uint32_t* mm = at_view(a.pre_minmax, a.g_stride, (uint32_t)(v_first + (int)threadIdx.x));
+        mm[blockIdx.x] = lo01 < lo23 ? lo01 : lo23;
+        mm[a.n_pre + blockIdx.x] = hi01 > hi23 ? hi01 : hi23;
     }
 }
 
@@ -287,6 +317,7 @@ int launch_preprocess(const Launch& L, const gsr_params& p, const Batch& B, int*
     a.scales = p.scales; a.rotations = p.rotations; a.cov3D_precomp = p.cov3D_precomp;
     a.view = p.viewmatrix; a.proj = p.projmatrix; a.campos = p.campos;
     a.splat = g.splat; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped;
+    a.pre_minmax = g.pre_minmax; a.n_pre = (int)div_up(p.P, PRE_THREADS);
     a.dkey = g.dkey[0]; a.radii = radii; a.counters = g.counters; a.grad_rec = B.grad_rec; a.gr_stride = B.gr_stride;
     a.g_zero = g.zero_begin; a.g_zero_bytes = g.zero_bytes; a.g_stride = B.g_stride;
     a.iv_zero = B.iv.zero_begin; a.iv_zero_bytes = B.iv.zero_bytes; a.iv_stride = B.iv_stride;

@@ -553,10 +553,15 @@ __device__ __forceinline__ void swap_halves2(float& a_lo, float& a_hi, float& b_
 {
     // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Called with x == y == v (two registers holding the same
     // per-lane value): afterwards x holds the LOWER half's v in all 64 lanes (lane i and lane i + 32 both have lane i's), y the upper
-    // half's.  hipcc pads no wait states inside asm: the statement carries its own s_nop 1 in front (VALU write -> permlane
-    // swap read: 2 wait states on gfx950) and behind (swap write -> VALU read).
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
-                 : "+v"(a_lo), "+v"(a_hi), "+v"(b_lo), "+v"(b_hi));
+    // half's.  Through the compiler's builtin (gfx950 only, like this whole library: common.hpp refuses other targets), so that the
+    // hazard recogniser pads the wait states around the swap (VALU write -> swap read and swap write -> VALU read) whatever the
+    // surrounding code becomes; earlier rounds carried hand-counted s_nop in inline asm.
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_lo), __float_as_uint(a_hi), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(b_lo), __float_as_uint(b_hi), false, false);
+    a_lo = __uint_as_float(a[0]);
+    a_hi = __uint_as_float(a[1]);
+    b_lo = __uint_as_float(b[0]);
+    b_hi = __uint_as_float(b[1]);
 }
 
 __global__ __launch_bounds__(64) void k_render_forward_half(RenderArgs a)

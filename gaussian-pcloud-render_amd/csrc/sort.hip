@@ -11,7 +11,14 @@
 // stride; a problem's element count may live on the device (the tile sort's num_rendered is never read back mid-frame):
 // the grid is sized by the arena capacity and workgroups past the count leave at once.
 //
-// One pass = three launches: per-workgroup digit histogram, per-digit row scan, stable scatter.
+// Two ways to run a pass (same kernels' ranking code, bit-identical results; launch_* at the end of the file choose):
+//   * three launches -- per-workgroup digit histogram, per-digit row scan, stable scatter: least traffic, the choice for
+//     batches (thousands of workgroups in flight hide the launch boundaries);
+//   * single-read histogram + look-back ("onesweep"): ONE kernel reads the keys once and counts the digits of every pass
+//     (k_depth_hist / k_tile_hist), then a pass is ONE scatter launch whose workgroups look back at the counts published by
+//     the workgroups before them (common.hpp LB_*): 1 + passes launches instead of 3 x passes -- the choice for single-view
+//     submissions, whose sort stages are bound by launch latency, not by bandwidth (replaces the reference's
+//     cub::DeviceRadixSort::SortPairs, CR/rasterizer_impl.cu:303-308, and its scan, :277).
 // The scatter ranks keys with wave64 ballots (one ballot per digit bit), reorders the workgroup's 4096
 // pairs in LDS, then writes digit runs with consecutive lanes on consecutive addresses.  The key bits
 // are split evenly over the passes (13 bits -> 7 + 6, not 8 + 5): narrower digits mean fewer ballots
@@ -232,31 +239,79 @@ int debug_scatter_times(unsigned long long* out8, int reset)
 #define SC_PUT(i, v) do { } while (0)
 #endif
 
+// ---- look-back bookkeeping of one pass (common.hpp LB_*) ------------------------------------------
+__device__ __forceinline__ uint32_t agent_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct LbArgs {
+    uint32_t* status;        // view 0's bookkeeping of THIS pass (the key arrays' arena: stride sv.stride)
+    const uint32_t* ghist;   // view 0's digit totals of this pass [RADIX]
+    size_t ghist_stride;
+    uint64_t* counters;      // view 0's CNT_* words (geometry arena) and the host's landing zone: a spin that gives up says so
+    size_t cnt_stride;
+    uint64_t* host_land;
+    uint32_t nblk_cap;       // rows the bookkeeping was laid out for
+    int tickets;             // number the blocks by a ticket drawn at their start instead of by blockIdx (common.hpp block_tickets)
+};
+
+// a published word is count + 1; polls until it is there (bounded: seconds -- then the frame is reported as failed, not hung)
+__device__ __forceinline__ uint32_t lb_wait(const uint32_t* p, uint32_t v, const LbArgs& lb, uint32_t view)
+{
+    uint32_t spins = 0;
+    while (v == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        v = agent_load32(p);
+        if (v == 0u && ++spins > (1u << 22)) {
+            at_view(lb.counters, lb.cnt_stride, view)[CNT_STALL] = 1;
+            if (lb.host_land) lb.host_land[4 * view + CNT_STALL] = 1;
+            v = 1u;
+        }
+    }
+    return v - 1u;
+}
+
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
-template <int BITS, typename KeyT, int RS_ITEMS>
+// LB = false: the block's per-digit offsets come from the count matrix the row scan left (hist / totals).
+// LB = true : no count matrix -- blocks publish their digit counts and sum what the blocks before them published (two-level,
+//             flat: see common.hpp).  A block only ever waits for lower-numbered blocks (common.hpp block_tickets: why that ends).
+template <int BITS, typename KeyT, int RS_ITEMS, bool LB>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index
                                                               KeyT* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, SortView sv, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ hist,
-                                                              const uint32_t* __restrict__ totals, int nblk_pad)
+                                                              const uint32_t* __restrict__ totals, int nblk_pad, LbArgs lb)
 {
     constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const uint32_t view = blockIdx.y;
     uint32_t kbase;
     if (!pass_control(sv, view, shift, kbase)) return;
     const int64_t n = view_count(sv, view);
-    // Workgroup -> sort block: the HIST_GROUP blocks whose counters share a 64-B line of the count matrix run on ONE XCD
-    // (workgroup w runs on XCD w % 8), so the line is fetched into that L2 once instead of by sixteen different L2s.
-    const uint32_t wg = blockIdx.x, xcd = wg & 7u, r = wg >> 3;
-    const uint32_t blk = ((r / HIST_GROUP) * 8u + xcd) * HIST_GROUP + (r % HIST_GROUP);
+    uint32_t blk;
+    uint32_t* lb_status = nullptr;
+    if constexpr (LB) {
+        __shared__ uint32_t s_ticket;
+        lb_status = at_view(lb.status, sv.stride, view);
+        blk = blockIdx.x;
+        if (lb.tickets) {   // (wave-uniform)
+            if (threadIdx.x == 0) s_ticket = atomicAdd(&lb_status[0], 1u);
+            __syncthreads();
+            blk = s_ticket;
+        }
+        totals = at_view(lb.ghist, lb.ghist_stride, view);
+    } else {
+        // Workgroup -> sort block: the HIST_GROUP blocks whose counters share a 64-B line of the count matrix run on ONE XCD
+        // (workgroup w runs on XCD w % 8), so the line is fetched into that L2 once instead of by sixteen different L2s.
+        const uint32_t wg = blockIdx.x, xcd = wg & 7u, r = wg >> 3;
+        blk = ((r / HIST_GROUP) * 8u + xcd) * HIST_GROUP + (r % HIST_GROUP);
+        hist = at_view(hist, sv.stride, view);
+        totals = at_view(totals, sv.stride, view);
+    }
     if ((int64_t)blk * RS_TILE >= n) return;
     keys_in = at_view(keys_in, sv.stride, view);
     if (vals_in) vals_in = at_view(vals_in, sv.stride, view);
     keys_out = at_view(keys_out, sv.stride, view);
     vals_out = at_view(vals_out, sv.stride, view);
-    hist = at_view(hist, sv.stride, view);
-    totals = at_view(totals, sv.stride, view);
     __shared__ uint32_t s_key[RS_TILE];
     __shared__ uint32_t s_val[RS_TILE];
     __shared__ uint32_t wave_cnt[RS_WAVES][RADIX];  // running per-wave digit counts, then exclusive over waves
@@ -273,7 +328,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
 
     // requested before the keys (loads return in order): see gbase_d below
     const uint32_t tot_d = tid <= mask ? totals[tid] : 0u;
-    const uint32_t hist_d = tid <= mask ? hist[(size_t)tid * nblk_pad + blk] : 0u;
+    uint32_t hist_d = 0u;
+    if constexpr (!LB) hist_d = tid <= mask ? hist[(size_t)tid * nblk_pad + blk] : 0u;
 
     uint32_t k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
     const bool full = blk_base + RS_TILE <= n;   // all but the last block of a view: no bounds checks
@@ -304,7 +360,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     // digit d = tid: first global slot of this workgroup's digit-d run = digits below d in the whole array + digit d in the
     // blocks before this one.  Needs nothing from the keys: the two loads and the scan overlap the key loads' latency instead
     // of sitting between ranking and reorder (a fifth of the workgroup's life there, scripts/dup_times.py).
-    const uint32_t gbase_d = block_exclusive_scan_256(tot_d, tmp, nullptr) + hist_d;
+    uint32_t gbase_d = block_exclusive_scan_256(tot_d, tmp, nullptr) + hist_d;
     __builtin_amdgcn_wave_barrier();
 #ifdef GSR_STATS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,6 +396,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
     SC_PUT(1, t2 - t1);
 
     // digit d = tid: exclusive prefix over waves, workgroup-local and global run starts
+    uint32_t lb_run = 0u;
     {
         const uint32_t d = tid;
         uint32_t c[RS_WAVES], run = 0;
@@ -349,8 +406,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
             wave_cnt[i][d] = run;
             run += c[i];
         }
-        const uint32_t lb = block_exclusive_scan_256(run, tmp, nullptr);
-        local_base[d] = lb;
+        if constexpr (LB) {
+            // publish this block's count of digit d right away: the blocks behind this one wait for it
+            if (d <= mask) agent_store32(&lb_status[LB_HDR + blk * (mask + 1u) + d], run + 1u);
+            lb_run = run;
+        }
+        const uint32_t lbase = block_exclusive_scan_256(run, tmp, nullptr);
+        local_base[d] = lbase;
         global_base[d] = gbase_d;
     }
     __syncthreads();
@@ -367,6 +429,42 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
         }
     }
     __syncthreads();
+    if constexpr (LB) {
+        // Look back, now that the pairs wait in LDS and their registers are free: add up what came before this block -- the sums
+        // of the groups before its group and the counts of the earlier blocks of its own group (final when first seen non-zero;
+        // they were published while this block reordered).  nd divides 256: 256 / nd threads share a digit's rows.
+        const uint32_t d = tid, nd = mask + 1u, ndl = (uint32_t)__builtin_ctz(nd);
+        const uint32_t G = blk / LB_GROUP, r = blk % LB_GROUP;
+        const uint32_t dd = d & mask, part = d >> ndl, parts = (uint32_t)RS_THREADS >> ndl, rows = G + r;
+        uint32_t sum_prev = 0u, sum_own = 0u;
+        constexpr uint32_t LBU = 8;   // rows requested back to back: one round trip for LBU of them
+        // row -> word offset from the pass' bookkeeping (32-bit: the whole of it is < 2^21 words)
+        const uint32_t grp_w = LB_HDR + lb.nblk_cap * nd + dd, own_w = LB_HDR + (G * LB_GROUP - G) * nd + dd;
+        for (uint32_t row0 = part; row0 < rows; row0 += parts * LBU) {
+            uint32_t v[LBU];
+#pragma unroll
+            for (uint32_t k = 0; k < LBU; k++) {
+                const uint32_t row = row0 + k * parts;
+                v[k] = row < rows ? agent_load32(lb_status + ((row < G ? grp_w : own_w) + row * nd)) : 1u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < LBU; k++) {
+                const uint32_t row = row0 + k * parts;
+                const uint32_t c = v[k] != 0u ? v[k] - 1u : lb_wait(lb_status + ((row < G ? grp_w : own_w) + row * nd), 0u, lb, view);
+                if (row < G) sum_prev += c; else sum_own += c;
+            }
+        }
+        wave_cnt[0][d] = sum_prev;   // (the per-wave counts have been consumed by the reorder above)
+        wave_cnt[1][d] = sum_own;
+        __syncthreads();
+        if (d < nd) {
+            uint32_t prev = 0u, own = 0u;
+            for (uint32_t q = 0; q < parts; q++) { prev += wave_cnt[0][q * nd + d]; own += wave_cnt[1][q * nd + d]; }
+            global_base[d] += prev + own;
+            if (r == LB_GROUP - 1) agent_store32(&lb_status[LB_HDR + (lb.nblk_cap + G) * nd + d], own + lb_run + 1u);
+        }
+        __syncthreads();
+    }
     SC_T(t4);
     SC_PUT(3, t4 - t3);
 
@@ -386,6 +484,180 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __rest
 #ifdef GSR_STATS
     { SC_T(t5); SC_PUT(4, t5 - t4); }
 #endif
+}
+
+
+// ================================================================================================================================
+// Single-read histograms + look-back passes
+// ================================================================================================================================
+constexpr int HIST_THREADS = 1024;
+
+// ---- depth keys: key range -> control words, digit totals of every pass, bookkeeping cleared -------------------------------
+// grid (G, V).  Every workgroup reduces the per-workgroup key extremes k_preprocess left (n_pre records: a few KB from the L2)
+// to the frame's control words -- base = smallest key of a Gaussian that emits pairs with its low 8 bits cleared, bits =
+// position of the highest bit in which (largest key - base) is set: depths within a factor of two of each other differ in at
+// most 24 bits, and the passes above `bits` leave at once -- then counts the digits of (key - base) for the passes that run in
+// its slice of the keys (LDS, four copies) and adds them to the view's totals.  The look-back words of the passes are cleared
+// here (the scatters run behind this kernel).
+struct DepthHistArgs {
+    const uint32_t* keys;
+    const uint32_t* pre_minmax;
+    uint32_t* sortctl;
+    uint32_t* ghist;
+    uint32_t* lb;
+    size_t stride;
+    size_t lb_words;    // of all four passes
+    int P, n_pre;
+};
+
+__global__ __launch_bounds__(HIST_THREADS) void k_depth_hist(DepthHistArgs a)
+{
+    const uint32_t view = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t* mm = at_view(a.pre_minmax, a.stride, view);
+    __shared__ uint32_t s_min, s_max;
+    __shared__ uint32_t h[4][4][RADIX];   // [pass][copy][digit]
+    if (tid == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; }
+    for (uint32_t i = tid; i < 4u * 4u * RADIX; i += HIST_THREADS) (&h[0][0][0])[i] = 0u;
+    __syncthreads();
+    {
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (int b = (int)tid; b < a.n_pre; b += HIST_THREADS) {
+            const uint32_t x = mm[b], y = mm[a.n_pre + b];
+            kmin = x < kmin ? x : kmin;
+            kmax = y > kmax ? y : kmax;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t x = __shfl_xor(kmin, d, 64), y = __shfl_xor(kmax, d, 64);
+            kmin = x < kmin ? x : kmin;
+            kmax = y > kmax ? y : kmax;
+        }
+        if (lane == 0) { atomicMin(&s_min, kmin); atomicMax(&s_max, kmax); }
+    }
+    __syncthreads();
+    const uint32_t base = s_min <= s_max ? (s_min & ~(uint32_t)(RADIX - 1)) : 0u;
+    const uint32_t span = s_min <= s_max ? s_max - base : 0u;       // no visible Gaussian: one pass, any order
+    uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+    bits = bits < (uint32_t)RADIX_BITS ? (uint32_t)RADIX_BITS : bits;
+    const uint32_t npass = depth_sort_passes(bits);
+    if (blockIdx.x == 0 && tid == 0) {
+        uint32_t* c = at_view(a.sortctl, a.stride, view);
+        c[SORTCTL_BASE] = base;
+        c[SORTCTL_BITS] = bits;
+    }
+    zero_region(reinterpret_cast<char*>(at_view(a.lb, a.stride, view)), a.lb_words * sizeof(uint32_t),
+                (size_t)blockIdx.x * HIST_THREADS + tid, (size_t)gridDim.x * HIST_THREADS);
+    // this workgroup's slice of the keys, in 16-B loads
+    const uint32_t* keys = at_view(a.keys, a.stride, view);
+    const int64_t n4 = (a.P + 3) / 4;
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = per * blockIdx.x, q1 = q0 + per < n4 ? q0 + per : n4;
+    const uint32_t copy = (tid >> 6) & 3u;
+    for (int64_t q = q0 + tid; q < q1; q += HIST_THREADS) {
+        uint32_t k[4];
+        if (4 * q + 3 < a.P) {
+            const uint4 v = reinterpret_cast<const uint4*>(keys)[q];
+            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) k[j] = 4 * q + j < a.P ? keys[4 * q + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (4 * q + j >= a.P) break;
+            const uint32_t rel = k[j] - base;
+            atomicAdd(&h[0][copy][rel & 0xFFu], 1u);
+            if (npass > 1) atomicAdd(&h[1][copy][(rel >> 8) & 0xFFu], 1u);
+            if (npass > 2) atomicAdd(&h[2][copy][(rel >> 16) & 0xFFu], 1u);
+            if (npass > 3) atomicAdd(&h[3][copy][rel >> 24], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = at_view(a.ghist, a.stride, view);
+    for (uint32_t i = tid; i < npass * RADIX; i += HIST_THREADS) {
+        const uint32_t p = i >> RADIX_BITS, d = i & (RADIX - 1);
+        const uint32_t c = h[p][0][d] + h[p][1][d] + h[p][2][d] + h[p][3][d];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
+// ---- tile keys: pairs per tile (-> the tile ranges, binning.hip), digit totals of both passes, bookkeeping cleared -----------
+// grid (G, V), dynamic LDS = 4 << bits bytes.  ONE LDS atomic per key into a histogram over the whole key (the tile id, < 2^bits
+// <= LB_MAX_TILES); the digit totals of the two passes are row / column sums of that histogram.  Keys arrive in emission order
+// -- row-major runs of consecutive tile ids per Gaussian -- so the lanes of a wave mostly hit different bins.
+struct TileHistArgs {
+    const void* keys;          // u16 or u32
+    const uint64_t* n_dev;     // the view's pair count (geometry arena)
+    size_t n_stride;
+    int64_t cap;
+    size_t b_stride;
+    uint32_t* tile_count;      // [T]        } image arena, cleared by k_preprocess / the host on a resume
+    uint32_t* ghist;           // [2][RADIX] }
+    size_t iv_stride;
+    uint32_t* lb;
+    size_t lb_words;
+    int T, bits, bits0;        // key bits in all, bits of pass 0's digit
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(HIST_THREADS) void k_tile_hist(TileHistArgs a)
+{
+    extern __shared__ uint32_t th[];
+    const uint32_t view = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nbins = 1u << a.bits;
+    for (uint32_t i = tid; i < nbins; i += HIST_THREADS) th[i] = 0u;
+    zero_region(reinterpret_cast<char*>(at_view(a.lb, a.b_stride, view)), a.lb_words * sizeof(uint32_t),
+                (size_t)blockIdx.x * HIST_THREADS + tid, (size_t)gridDim.x * HIST_THREADS);
+    const uint64_t n64 = *at_view(a.n_dev, a.n_stride, view);
+    const int64_t n = n64 < (uint64_t)a.cap ? (int64_t)n64 : a.cap;
+    __syncthreads();
+    constexpr int KPL = 16 / (int)sizeof(KeyT);   // keys per 16-B load
+    const KeyT* keys = at_view(reinterpret_cast<const KeyT*>(a.keys), a.b_stride, view);
+    const int64_t nq = (n + KPL - 1) / KPL;
+    const int64_t per = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = per * blockIdx.x, q1 = q0 + per < nq ? q0 + per : nq;
+    for (int64_t q = q0 + tid; q < q1; q += HIST_THREADS) {
+        if ((q + 1) * KPL <= n) {
+            const uint4 v = reinterpret_cast<const uint4*>(keys)[q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (sizeof(KeyT) == 2) {
+                    atomicAdd(&th[w[j] & 0xFFFFu], 1u);
+                    atomicAdd(&th[w[j] >> 16], 1u);
+                } else {
+                    atomicAdd(&th[w[j]], 1u);
+                }
+            }
+        } else {
+            for (int j = 0; j < KPL; j++)
+                if (q * KPL + j < n) atomicAdd(&th[(uint32_t)keys[q * KPL + j]], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* tc = at_view(a.tile_count, a.iv_stride, view);
+    for (uint32_t t = tid; t < (uint32_t)a.T; t += HIST_THREADS) {
+        const uint32_t c = th[t];
+        if (c) atomicAdd(&tc[t], c);
+    }
+    // digit totals: pass 0 = the low bits0 bits (sum over the high part: lanes on consecutive bins), pass 1 = the rest (a wave per
+    // digit: lanes on consecutive bins of the digit's row, then a wave reduction)
+    uint32_t* gh = at_view(a.ghist, a.iv_stride, view);
+    const uint32_t nd0 = 1u << a.bits0, nd1 = nbins >> a.bits0;
+    for (uint32_t d = tid; d < nd0; d += HIST_THREADS) {
+        uint32_t c = 0;
+        for (uint32_t hi = 0; hi < nd1; hi++) c += th[(hi << a.bits0) | d];
+        if (c) atomicAdd(&gh[d], c);
+    }
+    if (nd1 > 1u) {
+        for (uint32_t d = tid >> 6; d < nd1; d += HIST_THREADS / 64) {
+            uint32_t c = 0;
+            for (uint32_t lo = lane; lo < nd0; lo += 64u) c += th[(d << a.bits0) | lo];
+#pragma unroll
+            for (int x = 32; x >= 1; x >>= 1) c += __shfl_xor(c, x, 64);
+            if (lane == 0 && c) atomicAdd(&gh[RADIX + d], c);
+        }
+    }
 }
 
 // Sorts on key bits [0, end_bit).  job.key[0]/val[0] hold the input (val[0] ignored when iota_vals); the
@@ -428,18 +700,18 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
 #define GSR_SCATTER(B)                                                                                                        \
     case B:                                                                                                                   \
         if (key16)                                                                                                            \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t, RS_ITEMS>), grid, dim3(RS_THREADS), 0, L.stream,                 \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t, RS_ITEMS, false>), grid, dim3(RS_THREADS), 0, L.stream,          \
                                (const uint16_t*)job.key[cur], vin, (uint16_t*)job.key[cur ^ 1], job.val[cur ^ 1], sv, shift,  \
-                               mask, job.hist, job.totals, nblk_pad);                                                         \
+                               mask, job.hist, job.totals, nblk_pad, LbArgs{});                                               \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t, RS_ITEMS>), grid, dim3(RS_THREADS), 0, L.stream,                 \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t, RS_ITEMS, false>), grid, dim3(RS_THREADS), 0, L.stream,          \
                                (const uint32_t*)job.key[cur], vin, job.key[cur ^ 1], job.val[cur ^ 1], sv, shift, mask,       \
-                               job.hist, job.totals, nblk_pad);                                                               \
+                               job.hist, job.totals, nblk_pad, LbArgs{});                                                     \
         break;
             if (small)
-                hipLaunchKernelGGL((k_radix_scatter<RADIX_BITS, uint32_t, RS_ITEMS_SMALL>), grid, dim3(RS_THREADS), 0, L.stream,
+                hipLaunchKernelGGL((k_radix_scatter<RADIX_BITS, uint32_t, RS_ITEMS_SMALL, false>), grid, dim3(RS_THREADS), 0, L.stream,
                                    (const uint32_t*)job.key[cur], vin, job.key[cur ^ 1], job.val[cur ^ 1], sv, shift, mask, job.hist,
-                                   job.totals, nblk_pad);
+                                   job.totals, nblk_pad, LbArgs{});
             else switch (bits) {
                 GSR_SCATTER(1) GSR_SCATTER(2) GSR_SCATTER(3) GSR_SCATTER(4) GSR_SCATTER(5) GSR_SCATTER(6) GSR_SCATTER(7)
                 GSR_SCATTER(8)
@@ -454,6 +726,108 @@ int launch_radix_sort_pairs(const Launch& L, const SortJob& job, bool iota_vals,
         cur = ((end_bit + RADIX_BITS - 1) / RADIX_BITS) & 1;
     }
     *result_buffer = cur;
+    return GSR_OK;
+}
+
+// ---- look-back launch sequences ----------------------------------------------------------------------------------------------
+// Depth sort: 1 + 4 launches (the passes above the frame's key bits leave at once, like the three-launch passes).  Same result
+// buffer convention: the ids in depth order end up in val[passes & 1].
+int launch_depth_sort_lookback(const Launch& L, const SortJob& job, const LbJob& lj)
+{
+    if (job.cap <= 0 || job.V <= 0) return GSR_OK;
+    const int P = (int)job.cap;
+    DepthHistArgs h;
+    h.keys = job.key[0];
+    h.pre_minmax = lj.pre_minmax;
+    h.sortctl = job.sortctl;
+    h.ghist = lj.ghist;
+    h.lb = lj.lb;
+    h.stride = job.stride;
+    h.lb_words = 4 * lj.pass_words;
+    h.P = P;
+    h.n_pre = (int)div_up(P, PRE_THREADS);
+    int G = (int)div_up(P, HIST_THREADS * 8);
+    G = G < 1 ? 1 : G > 64 ? 64 : G;
+    hipLaunchKernelGGL(k_depth_hist, dim3(G, job.V), dim3(HIST_THREADS), 0, L.stream, h);
+    if (int e = check_launch(L, "depth_hist")) return e;
+    SortView sv{job.stride, nullptr, 0, job.cap, job.sortctl};
+    const uint32_t nblk = (uint32_t)lb_blocks(job.cap);
+    int cur = 0;
+    for (int pass = 0; pass < 4; pass++) {
+        LbArgs lb{lj.lb + (size_t)pass * lj.pass_words, lj.ghist + pass * RADIX, lj.ghist_stride, lj.counters, lj.cnt_stride, lj.host_land, nblk, block_tickets(-1)};
+        hipLaunchKernelGGL((k_radix_scatter<RADIX_BITS, uint32_t, RS_ITEMS, true>), dim3(nblk, job.V), dim3(RS_THREADS), 0, L.stream,
+                           (const uint32_t*)job.key[cur], pass == 0 ? (const uint32_t*)nullptr : (const uint32_t*)job.val[cur],
+                           job.key[cur ^ 1], job.val[cur ^ 1], sv, pass * RADIX_BITS, (uint32_t)(RADIX - 1), (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, 0, lb);
+        if (int e = check_launch(L, "radix_scatter_lookback")) return e;
+        cur ^= 1;
+    }
+    return GSR_OK;
+}
+
+// Tile sort on key bits [0, end_bit), end_bit <= 15: 1 + (1 or 2) launches; also leaves the pairs per tile in lj.tile_count.
+// The result lands in key / val[*result_buffer] like launch_radix_sort_pairs.
+int launch_tile_sort_lookback(const Launch& L, const SortJob& job, const LbJob& lj, int T, int end_bit, int* result_buffer, bool key16)
+{
+    const int npass = (end_bit + RADIX_BITS - 1) / RADIX_BITS;
+    *result_buffer = npass & 1;
+    if (job.cap <= 0 || job.V <= 0) return GSR_OK;
+    const int bits0 = (end_bit + npass - 1) / npass;   // even split, wider digit first (= launch_radix_sort_pairs)
+    TileHistArgs h;
+    h.keys = job.key[0];
+    h.n_dev = job.n_dev;
+    h.n_stride = job.n_stride;
+    h.cap = job.cap;
+    h.b_stride = job.stride;
+    h.tile_count = lj.tile_count;
+    h.ghist = const_cast<uint32_t*>(lj.ghist);
+    h.iv_stride = lj.ghist_stride;
+    h.lb = lj.lb;
+    h.lb_words = (size_t)npass * lj.pass_words;
+    h.T = T;
+    h.bits = end_bit;
+    h.bits0 = bits0;
+    int G = (int)div_up(job.cap, (int64_t)HIST_THREADS * 64);
+    G = G < 1 ? 1 : G > 128 ? 128 : G;
+    const size_t lds = (size_t)4 << end_bit;
+    static const bool lds_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_hist<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 15) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_hist<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 15) == hipSuccess;
+    }();
+    (void)lds_ok;
+    if (key16)
+        hipLaunchKernelGGL(k_tile_hist<uint16_t>, dim3(G, job.V), dim3(HIST_THREADS), lds, L.stream, h);
+    else
+        hipLaunchKernelGGL(k_tile_hist<uint32_t>, dim3(G, job.V), dim3(HIST_THREADS), lds, L.stream, h);
+    if (int e = check_launch(L, "tile_hist")) return e;
+    SortView sv{job.stride, job.n_dev, job.n_stride, job.cap, nullptr};
+    const uint32_t nblk = (uint32_t)lb_blocks(job.cap);
+    int cur = 0, shift = 0;
+    for (int pass = 0; pass < npass; pass++) {
+        const int bits = pass == 0 ? bits0 : end_bit - bits0;
+        const uint32_t mask = (1u << bits) - 1u;
+        LbArgs lb{lj.lb + (size_t)pass * lj.pass_words, lj.ghist + pass * RADIX, lj.ghist_stride, lj.counters, lj.cnt_stride, lj.host_land, nblk, block_tickets(-1)};
+        const dim3 grid(nblk, job.V);
+#define GSR_SCATTER_LB(B)                                                                                                     \
+    case B:                                                                                                                   \
+        if (key16)                                                                                                            \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint16_t, RS_ITEMS, true>), grid, dim3(RS_THREADS), 0, L.stream,           \
+                               (const uint16_t*)job.key[cur], (const uint32_t*)job.val[cur], (uint16_t*)job.key[cur ^ 1],     \
+                               job.val[cur ^ 1], sv, shift, mask, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, lb); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_radix_scatter<B, uint32_t, RS_ITEMS, true>), grid, dim3(RS_THREADS), 0, L.stream,           \
+                               (const uint32_t*)job.key[cur], (const uint32_t*)job.val[cur], job.key[cur ^ 1],                \
+                               job.val[cur ^ 1], sv, shift, mask, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0, lb); \
+        break;
+        switch (bits) {
+            GSR_SCATTER_LB(1) GSR_SCATTER_LB(2) GSR_SCATTER_LB(3) GSR_SCATTER_LB(4) GSR_SCATTER_LB(5) GSR_SCATTER_LB(6) GSR_SCATTER_LB(7)
+            GSR_SCATTER_LB(8)
+        }
+#undef GSR_SCATTER_LB
+        if (int e = check_launch(L, "radix_scatter_lookback")) return e;
+        cur ^= 1;
+        shift += bits;
+    }
     return GSR_OK;
 }
 

@@ -35,7 +35,7 @@ SYMBOLS = ("gsr_geom_bytes", "gsr_geom_bytes_inference", "gsr_image_bytes", "gsr
            "gsr_forward_stage2", "gsr_backward_batch", "gsr_backward", "gsr_mark_visible", "gsr_query", "gsr_set_profiling",
            "gsr_get_profile", "gsr_last_error", "gsr_version", "gsr_selftest", "gsr_forward_recolor", "gsr_forward_batch_channels", "gsr_d2h_count",
            "gsr_clock_probe_launch", "gsr_wall_clock_khz", "gsr_last_list_pairs", "gsr_set_forward_half_views",
-           "gsr_set_backward_moments")
+           "gsr_set_backward_moments", "gsr_set_sort_mode")
 
 GSR_RETRY = 1
 
@@ -88,6 +88,8 @@ def _load():
     lib.gsr_set_forward_half_views.argtypes = [C.c_int]
     lib.gsr_set_backward_moments.restype = C.c_int
     lib.gsr_set_backward_moments.argtypes = [C.c_int]
+    lib.gsr_set_sort_mode.restype = C.c_int
+    lib.gsr_set_sort_mode.argtypes = [C.c_int, C.c_int]
     lib.gsr_get_profile.restype = C.c_int
     lib.gsr_get_profile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.gsr_selftest.restype = C.c_int

@@ -244,6 +244,14 @@ long long gsr_d2h_count(void);
  * 8 x 8 kernel always; views < 0 only queries.  Returns the value in force. */
 int gsr_set_forward_half_views(int views);
 
+/* Tuning / test hook: how the two sorts of a submission run (csrc/sort.hip; the sorted lists are bit-identical either way).
+ * mode 0: three launches per radix pass (digit histogram per block, row scan, stable scatter) -- least traffic; 1: one kernel reads
+ * the keys once and counts the digits of every pass, then ONE scatter launch per pass whose workgroups look back at the counts of
+ * the workgroups before them ("onesweep"), and the tile ranges are prefix sums of the per-tile counts -- 12 launches per single-view
+ * forward instead of 23; 2 (default; GSR_SORT_MODE): look-back passes for submissions of up to `lookback_views` views (default 2;
+ * GSR_SORT_LB_VIEWS), three-launch passes for larger batches.  mode < 0 / lookback_views < 0 leave the setting.  Returns the mode. */
+int gsr_set_sort_mode(int mode, int lookback_views);
+
 /* Accuracy / speed switch of the render backward's pixel contraction: 0 (default; GSR_BWD_SUBQ=0) second moments about the 8 x 8
  * quadrant centre; 1 about the centres of its four 4 x 4 sub-quadrants, each shifted to the splat centre on its own: the mean2D /
  * conic sums then carry the reference build's rounding error instead of 1.9x / 4x of it, for more arithmetic

@@ -155,3 +155,20 @@ def test_rasterize_views_validates_like_the_reference():
     st2 = st._replace(image_width=16)
     with pytest.raises(Exception, match="must share image size"):
         d.rasterize_views(m, m, m[:, :1], [st, st2], colors_precomp=m, scales=m, rotations=torch.zeros(2, 4))
+
+
+def test_a_missing_reference_build_fails_the_gpu_comparisons(monkeypatch):
+    """The -m gpu tests that compare with oracle/_ref must turn red, not yellow, when the .so did not travel to the GPU box."""
+    import _pytest.outcomes
+    import util
+    from oracle import oracle as orc
+    monkeypatch.setitem(orc.REF_SO, "strict", os.path.join(ROOT, "oracle", "_ref", "no_such_library.so"))
+    monkeypatch.delenv("GSR_ALLOW_NO_REF", raising=False)
+    with pytest.raises(_pytest.outcomes.Failed):
+        util.reference_build("strict")
+    monkeypatch.setenv("GSR_ALLOW_NO_REF", "1")
+    with pytest.raises(_pytest.outcomes.Skipped):
+        util.reference_build("strict")
+    monkeypatch.setenv("GSR_REQUIRE_REF", "1")
+    with pytest.raises(_pytest.outcomes.Failed):
+        util.reference_build("strict")

@@ -63,8 +63,7 @@ def _check(s, tag, oracle, gpu_device, ref):
 
 
 def _ref():
-    from oracle.oracle import Reference
-    return Reference("strict") if Reference.available("strict") else None
+    return util.reference_build("strict")
 
 
 @pytest.mark.parametrize("K", COUNTS)

@@ -32,10 +32,7 @@ def _t(a, dev):
 
 
 def _ref():
-    from oracle.oracle import Reference
-    if not Reference.available("strict"):
-        pytest.skip("oracle/_ref not built")
-    return Reference("strict")
+    return util.reference_build("strict")
 
 
 def _image_close(got, want, tag):

@@ -19,10 +19,7 @@ Z0 = 2.0
 
 
 def _ref():
-    from oracle.oracle import Reference
-    if not Reference.available("strict"):
-        pytest.skip("oracle/_ref not built")
-    return Reference("strict")
+    return util.reference_build("strict")
 
 
 def _targets():

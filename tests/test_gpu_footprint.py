@@ -20,10 +20,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ref():
-    from oracle.oracle import Reference
-    if not Reference.available("strict"):
-        pytest.skip("oracle/_ref not built")
-    return Reference("strict")
+    return util.reference_build("strict")
 
 
 @pytest.mark.parametrize("name", SCENES)

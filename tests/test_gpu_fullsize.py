@@ -33,10 +33,7 @@ def _scene(cfg, voxel_exact=False):
 
 
 def _ref():
-    from oracle.oracle import Reference
-    if not Reference.available("strict"):
-        pytest.skip("oracle/_ref not built")
-    return Reference("strict")
+    return util.reference_build("strict")
 
 
 @pytest.mark.parametrize("name", ["thuman256_1080p", "thuman800k_1080p", "mesh2m_4k"])

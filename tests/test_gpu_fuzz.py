@@ -33,10 +33,7 @@ MAX_ROW_FRACTION_REF_TOO = 4e-4
 
 
 def _ref():
-    from oracle.oracle import Reference
-    if not Reference.available("strict"):
-        pytest.skip("oracle/_ref not built")
-    return Reference("strict")
+    return util.reference_build("strict")
 
 
 def _case(i):

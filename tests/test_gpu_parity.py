@@ -25,10 +25,7 @@ MAX_FLIP_FRACTION = 2e-3
 
 
 def _ref(variant="strict"):
-    from oracle.oracle import Reference
-    if not Reference.available(variant):
-        pytest.skip("oracle/_ref/libgsr_ref_%s.so not built (needs /root/reference at build time)" % variant)
-    return Reference(variant)
+    return util.reference_build(variant)
 
 
 def _check_integers(p, o, tag):
@@ -221,6 +218,32 @@ def test_half_quadrant_forward_equals_the_8x8_kernel(name, gpu_device):
     for k in ga:
         if ga[k].size:
             assert np.abs(ga[k].astype(np.float64) - gb[k]).max() <= 2e-4 * (np.abs(ga[k]).max() + 1e-30), k   # (atomic order)
+
+
+@pytest.mark.parametrize("name", ["capsule_circle", "voxel_ties", "culled_mix", "deep_stack", "depth_span_1", "depth_span_3", "depth_span_4",
+                                  "all_culled", "one_gaussian"])
+def test_lookback_sort_mode_gives_the_same_lists(name, gpu_device):
+    """gsr_set_sort_mode(1): single-read histogram kernels + ONE look-back scatter launch per radix pass, tile ranges as prefix sums
+    of the per-tile histogram (csrc/sort.hip; opt-in: on this multi-XCD part the look-back costs more than the launches it saves,
+    profiles/r06_lookback_sort.txt).  Everything the two ways produce is the same bit for bit: lists with their tie order, ranges,
+    the depth sort's control words, images."""
+    from diff_gaussian_rasterization import _native as N
+    s = build_scene(name)
+    was = N.lib.gsr_set_sort_mode(-1, -1)
+    try:
+        assert N.lib.gsr_set_sort_mode(0, -1) == 0
+        a, _ = run_product(s, gpu_device)
+        assert N.lib.gsr_set_sort_mode(1, -1) == 1
+        b, _ = run_product(s, gpu_device)
+        c, _ = run_product(s, gpu_device, reference_lists=False)    # footprint-clipped lists through the same kernels
+        N.lib.gsr_set_sort_mode(0, -1)
+        d, _ = run_product(s, gpu_device, reference_lists=False)
+    finally:
+        N.lib.gsr_set_sort_mode(was, -1)
+    for x, y in ((a, b), (d, c)):
+        assert x["R"] == y["R"]
+        for k in ("out_color", "radii") + (("final_T", "n_contrib", "vals", "keys", "ranges", "depth_sort") if s.P else ()):
+            assert x[k].tobytes() == y[k].tobytes(), k
 
 
 def test_subquadrant_moments_mode_is_correct_and_more_accurate(oracle, gpu_device):

@@ -13,10 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _fast():
-    from oracle.oracle import Reference
-    if not Reference.available("fast"):
-        pytest.skip("oracle/_ref (fast variant) not built")
-    return Reference("fast")
+    return util.reference_build("fast")
 
 
 def _compare(name, s, gpu_device, light):

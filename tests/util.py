@@ -17,6 +17,27 @@ from pcrender import camera as cam  # noqa: E402
 from pcrender import synth  # noqa: E402
 
 
+# counts the comparisons made against the reference build in this process (smoke() and the fuzz tally print it)
+REF_USES = {"strict": 0, "fast": 0}
+
+
+def reference_build(variant="strict"):
+    """The reference's own kernels built for gfx950 (oracle/_ref/libgsr_ref_<variant>.so, made by oracle/build_ref.sh where
+    /root/reference exists; git-ignored, it rides to the GPU box with the push).  The -m gpu tests that compare against it are
+    most of the parity evidence, so a library that did not travel FAILS them -- a green run must not depend on luck.  Only
+    GSR_ALLOW_NO_REF=1 (a GPU machine that never had the reference mounted) turns the failure into a skip."""
+    import pytest
+    from oracle.oracle import REF_SO, Reference
+    if not Reference.available(variant):
+        msg = ("%s is missing: oracle/_ref/*.so did not travel (build it with oracle/build_ref.sh where /root/reference is "
+               "mounted; GSR_ALLOW_NO_REF=1 skips instead)" % REF_SO[variant])
+        if os.environ.get("GSR_ALLOW_NO_REF", "0") == "1" and os.environ.get("GSR_REQUIRE_REF", "0") != "1":
+            pytest.skip(msg)
+        pytest.fail(msg)
+    REF_USES[variant] += 1
+    return Reference(variant)
+
+
 def _view_arrays(H_c2w, W, H, fov_deg):
     import torch
     s = cam.raster_settings_arrays(torch.as_tensor(H_c2w, dtype=torch.float32), W, H, fov_deg, 1)
