@@ -320,6 +320,7 @@ def main():
         return img
 
     literal_mode = [False]
+    host_trace = None     # ([settings built], [C forward entered]) perf_counter stamps while drop_in_host_exposed runs
 
     def render_literal(i, tslot=0, with_grad=True):
         """The reference caller's loop body, literally (simple_raw_render.py:260-278): the settings of the view are BUILT for this
@@ -328,6 +329,8 @@ def main():
         v = view_of(i, rank, world, n_views, shard)
         L = leafsets[tslot]
         st = _rp.settings_for_view(H_c2w_views[v], W, H, 45.0, dev, sh_degree=D, bg=bg, super_sample_rate=1)
+        if host_trace is not None:
+            host_trace[0].append(time.perf_counter())
         if with_grad:
             img, _ = GaussianRasterizer(st)(**L)
             (img * G).sum().backward()
@@ -441,6 +444,35 @@ def main():
             literal_mode[0] = False
             _native.set_overlap(was)
         return frames / float(np.median(ts)), [round(frames / t, 1) for t in ts]
+
+    def drop_in_host_exposed(frames=96):
+        """Host time between the caller's last blocking copy (the settings are built) and the library's C entry point, which launches
+        the frame's first kernel at once: what the GPU idles through in every frame of the literal loop (the copies drain the stream).
+        Stamps around the real code path (the ctypes entry is wrapped for these frames only); scripts/literal_host_trace.py has the
+        layer-by-layer version."""
+        nonlocal host_trace
+        real = _native.lib.gsr_forward_batch
+        stamps = ([], [])
+
+        def stamped(*a):
+            stamps[1].append(time.perf_counter())
+            return real(*a)
+        was = _native._OVERLAP_ON
+        _native.set_overlap(False)
+        literal_mode[0] = True
+        try:
+            run_steps(0, 12, streams=1, vpc=1, gather_on=False)
+            torch.cuda.synchronize()
+            _native.lib.gsr_forward_batch, host_trace = stamped, stamps
+            run_steps(0, frames, streams=1, vpc=1, gather_on=False)
+            torch.cuda.synchronize()
+        finally:
+            _native.lib.gsr_forward_batch, host_trace = real, None
+            literal_mode[0] = False
+            _native.set_overlap(was)
+        d = np.array(stamps[1][:len(stamps[0])]) - np.array(stamps[0][:len(stamps[1])])
+        return {"mean": round(float(d.mean()) * 1e6, 1), "median": round(float(np.median(d)) * 1e6, 1), "frames": int(d.size),
+                "what": "settings built -> gsr_forward_batch entered (the entry launches the first kernel at once), literal per-view loop"}
 
     if args.drop_in_probe:
         # a fresh process measuring only the drop-in figure (spawned by the main run, --drop-in-processes)
@@ -589,6 +621,7 @@ def main():
         fps_lit, lit_blocks = drop_in_literal()
         drop_in["frames_per_s"]["literal"] = round(fps_lit, 1)
         drop_in["literal_blocks"] = lit_blocks
+        drop_in["host_exposed_us"] = drop_in_host_exposed()
         ovl_default = _native._OVERLAP_ON
         for name, st, ovl in (("one_stream_in_order", 1, False), ("one_stream_overlap_opt_in", 1, True), ("four_streams", 4, False)):
             if st > len(leafsets):
@@ -900,6 +933,7 @@ def main():
                 "what": "the reference caller's loop body as it stands (simple_raw_render.py:260-278): per view the settings are built "
                         "for the call (fresh tensors), GaussianRasterizer(settings)(means3D, means2D, opacities, shs=, scales=, "
                         "rotations=), loss.backward(); ONE thread, ONE stream, plain stream order (the library's default)",
+                "host_exposed_us": drop_in.get("host_exposed_us"),
                 "fresh_processes": drop_in.get("fresh_processes")},
             "reference_build_context": ref_ctx,
             "multi_gpu_status": "measured on %d GPU(s)" % world if (world > 1 and not host_collectives) else

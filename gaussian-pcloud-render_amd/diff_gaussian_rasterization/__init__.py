@@ -59,6 +59,18 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
         rs = raster_settings
+        if not rs.debug:
+            # steady state of a per-view loop: the short path (_native.forward_view; None = take the general one below)
+            need_backward = any(ctx.needs_input_grad)
+            fast = _C.forward_view(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, need_backward)
+            if fast is not None:
+                num_rendered, color, radii, arenas, layout = fast
+                ctx.raster_settings, ctx.num_rendered, ctx.opacity_shape, ctx.layout = rs, num_rendered, tuple(opacities.shape), layout
+                if need_backward:
+                    ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, arenas)
+                ctx.mark_non_differentiable(radii)
+                return color, radii
+        ctx.layout = None
         # the native call's argument order = reference __init__.py:60-80
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
@@ -75,6 +87,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _):
         rs = ctx.raster_settings
+        if ctx.layout is not None:
+            colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, arenas = ctx.saved_tensors
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _C.backward_view(
+                rs, means3D, radii, colors_precomp, scales, rotations, cov3Ds_precomp, grad_out_color, sh, arenas, ctx.layout)
+            return (g_means3D, g_means2D, _or_none(g_sh, sh), _or_none(g_colors, colors_precomp), g_opacities.reshape(ctx.opacity_shape),
+                    _or_none(g_scales, scales), _or_none(g_rotations, rotations), _or_none(g_cov3D, cov3Ds_precomp), None)
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
         # the native call's argument order = reference __init__.py:109-129
@@ -108,9 +126,32 @@ _ABSENT = torch.Tensor([])
 
 
 class GaussianRasterizer(nn.Module):
+    """nn.Module like the reference's (no parameters, no buffers: the settings are its only state).  The reference's caller builds one
+    PER CALL (simple_raw_render.py:263), between the copies that drain the stream and the first kernel, so construction and call are
+    kept off nn.Module's bookkeeping until something asks for it: nn.Module.__init__ (a dozen dictionaries) runs on the first access
+    to module state -- hooks, .to(), state_dict(), children ... -- and a module nobody has touched that way is called straight
+    through to forward (there can be no hooks on it)."""
+
     def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        object.__setattr__(self, "raster_settings", raster_settings)
+
+    def __getattr__(self, name):
+        if "_parameters" not in self.__dict__:          # nn.Module state asked for: build it now
+            rs = self.__dict__.pop("raster_settings")
+            nn.Module.__init__(self)
+            object.__setattr__(self, "raster_settings", rs)
+            return getattr(self, name)
+        return nn.Module.__getattr__(self, name)
+
+    def __setattr__(self, name, value):
+        if "_parameters" not in self.__dict__:
+            self.__getattr__("_parameters")
+        nn.Module.__setattr__(self, name, value)
+
+    def __call__(self, *args, **kwargs):
+        if "_parameters" not in self.__dict__:
+            return self.forward(*args, **kwargs)
+        return nn.Module.__call__(self, *args, **kwargs)
 
     def markVisible(self, positions):
         with torch.no_grad():
