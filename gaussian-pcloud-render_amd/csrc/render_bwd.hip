@@ -35,6 +35,9 @@
 namespace gsr {
 
 constexpr int BGRP = 4;  // entries evaluated per inner-loop trip
+#ifndef GSR_BWD_SUBQ_DEFAULT
+#define GSR_BWD_SUBQ_DEFAULT 2
+#endif
 
 #ifndef GSR_BWD_DIV
 #define GSR_BWD_DIV 1   // how T / (1 - alpha) is formed (see phase 1 of the group loop)
@@ -192,6 +195,39 @@ __device__ __forceinline__ void mm_contract4(const float* mrow, const float (&am
     }
 }
 
+// The adaptive mode keeps the quadrant-centre basis in `am` and takes the sub-quadrant one only for the batches that need it: about
+// its sub-quadrant's centre a basis polynomial depends on the step only through (r & 1, m & 1) -- x & 3 = 2 (r & 1) + (k & 1) --
+// so a lane needs FOUR values (bq), not sixteen; rows 12..14 (dL_dpixel, lanes with i >= 12) are the same in both bases.
+__device__ __forceinline__ void mm_basis_subq4(float (&bq)[4], uint32_t lane)
+{
+    const uint32_t i = lane & 15u, k = lane >> 4, c = i & 3u;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {   // h = 2 (m & 1) + (r & 1)
+        const float cx = (float)(2u * (uint32_t)(h & 1) + (k & 1u)) - 1.5f, cy = (float)(2u * (uint32_t)(h >> 1) + (k >> 1)) - 1.5f;
+        bq[h] = c == 0 ? 1.f : c == 1 ? cx : c == 2 ? cy : (i == 3 ? cx * cx : i == 7 ? cx * cy : cy * cy);
+    }
+}
+// one sub-quadrant (sq = 2 (m >> 1) + (r >> 1)) at a time: its four K steps into one accumulator (the adaptive mode's rare path
+// is written for few live registers, not for overlap)
+template <int SQ>
+__device__ __forceinline__ f32x4 mm_contract_sq(const float* mrow, const float (&am)[16], const float (&bq)[4], uint32_t lane,
+                                                unsigned long long blocks)
+{
+    const f32x4* rp = (const f32x4*)(mrow + (lane & 15u) * MM_STRIDE + 4u * (lane >> 4));
+    const bool poly = (lane & 15u) < 12u;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++) {
+        constexpr int r0 = 2 * (SQ & 1);
+        const int m = 2 * (SQ >> 1) + mm;
+        const f32x4 b = rp[4 * m];
+        const float e0 = poly ? bq[2 * (m & 1)] : am[4 * m + r0], e1 = poly ? bq[2 * (m & 1) + 1] : am[4 * m + r0 + 1];
+        if ((blocks >> (16 * m + 2 * r0)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, b[r0], acc, 0, 0, 0);
+        if ((blocks >> (16 * m + 2 * r0 + 2)) & 1ull) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e1, b[r0 + 1], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 #ifdef GSR_BWD_EMUL
 // DIAGNOSTIC build only (scripts/leases/gpu_session_r4b.sh): the same contraction as mm_contract by plain arithmetic, pixels in
 // raster order -- GSR_BWD_EMUL = 1: float fmaf chain, 2: double -- to tell the matrix cores' summation apart from the
@@ -338,10 +374,21 @@ struct RenderBwdArgs {
 
 // five waves per SIMD: 96 registers (the accumulator in VGPRs, five values of the item set-up spilled outside the hot
 // loops); the loop runs at ~70 % of the vector pipe with four waves, a fifth is worth 2.6 %
-template <bool SUBQ>
+// MODE: 0 moments about the quadrant centre; 1 about the four sub-quadrant centres; 2 ADAPTIVE: per batch of eight entries, the
+// sub-quadrant path only when one of them is flagged -- (b / sigma)^2 > SUBQ_M, b = splat centre - quadrant centre measured with the
+// splat's own conic (one compare when the entry is staged; the flag rides in bit 31 of the staged id).  The float32 rounding of
+// the quadrant-centred moments grows with that ratio; on the benchmark views no evaluated entry exceeds 20 (the alpha >= 1/255
+// footprint ends at ~17: scripts/analysis/subq_flag_hist.py), so their batches never pay, while sub-pixel splats seen from a
+// quadrant away -- where the 4x-the-reference errors of the conic gradient come from -- do.
+#ifndef GSR_SUBQ_M
+#define GSR_SUBQ_M 20.f
+#endif
+constexpr float SUBQ_M = GSR_SUBQ_M;
+template <int MODE>
 __attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
 {
+    constexpr bool SUBQ = MODE == 1;
     // Work items are (tile, chunk of BWD_CHUNK consumed list entries), one quadrant per wave; which ones a workgroup takes: see the
     // item loop.  XCD-aware either way: workgroup b runs on XCD b % 8 (each XCD has its own L2) and the four quadrant waves of an item
     // run on one XCD at about the same time, so the item's list slice and Splat records are fetched into that L2 once instead of
@@ -543,7 +590,13 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             if (touch) {
                 float* p = stage + (slot >> 2) * QUAD_WORDS + (slot & 3u);
                 p[0] = c0.x; p[4] = c0.y; p[8] = c0.z; p[12] = c0.w; p[16] = c1.x; p[20] = c1.y;
-                p[24] = c1.z; p[28] = c1.w; p[32] = c2b; p[36] = __builtin_bit_cast(float, id_cur);
+                uint32_t id_st = id_cur;
+                if constexpr (MODE == 2) {
+                    const float bx = c0.x - mm_sx, by = c0.y - mm_sy;
+                    const float mq = (c0.z * bx) * bx + 2.f * (c0.w * bx) * by + (c1.x * by) * by;
+                    id_st |= mq > SUBQ_M ? 0x80000000u : 0u;
+                }
+                p[24] = c1.z; p[28] = c1.w; p[32] = c2b; p[36] = __builtin_bit_cast(float, id_st);
             }
         }
         BWD_STAT(0, 1);
@@ -696,28 +749,44 @@ __global__ __launch_bounds__(64) void k_render_backward(RenderBwdArgs a)
             const uint32_t gq1 = (uint32_t)(quad > 0 ? quad - 1 : 0);   // the batch's second group, if it has one, was evaluated just now
             const float* e = stage + (mm_gb ? gq1 : gq0) * QUAD_WORDS + mm_k4;
             const float eX = e[0], eY = e[4], cP = e[mm_offP], cQ = e[mm_offQ], cO = e[20];
-            const uint32_t idA = __builtin_bit_cast(uint32_t, stage[gq0 * QUAD_WORDS + 36u + mm_k4]);
-            const uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
+            uint32_t idA = __builtin_bit_cast(uint32_t, stage[gq0 * QUAD_WORDS + 36u + mm_k4]);
+            uint32_t idB = __builtin_bit_cast(uint32_t, stage[gq1 * QUAD_WORDS + 36u + mm_k4]);
+            bool subq_batch = SUBQ;
+            if constexpr (MODE == 2) {   // (wave-uniform: every lane sees the same eight staged ids between them)
+                subq_batch = __builtin_amdgcn_ballot_w64(((idA | (nb == 2u ? idB : 0u)) >> 31) != 0u) != 0ull;
+                idA &= 0x7FFFFFFFu;
+                idB &= 0x7FFFFFFFu;
+            }
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink these loads behind the matrix instructions)
             // contraction over the 64 pixels, then every lane turns its four moments into (up to) three gradient values
             float o1, o2, o3;
-            if constexpr (SUBQ) {
+            if (MODE == 1 || (MODE == 2 && __builtin_expect(subq_batch, 0))) {
                 // moments about the four sub-quadrant centres (quadrant centre -+2 in x and y), each shifted to the splat centre on
                 // its own and then added: sum q dx^2 etc. lose (b / sigma)^2 of their bits with b the distance to the SUB-quadrant
                 // centre, and the sub-quadrants far from the splat carry little weight
-                f32x4 acc4[4];
-                mm_contract4(mrow, am, lane, hit_blocks, acc4);
                 const float bx = eX - mm_sx, by = eY - mm_sy;
-                const float bxs[2] = {bx + 2.f, bx - 2.f}, bys[2] = {by + 2.f, by - 2.f};
                 float S1 = 0.f, Dx = 0.f, Dy = 0.f, t2 = 0.f, Ay = 0.f, Az = 0.f;
-#pragma unroll
-                for (int sq = 0; sq < 4; sq++) {
-                    const float bxq = bxs[sq & 1], byq = bys[sq >> 1];
-                    const float s1 = acc4[sq].x, sx = acc4[sq].y, sy = acc4[sq].z, v3 = acc4[sq].w;
+                const auto shift_add = [&](const f32x4 acc, const float bxq, const float byq) {
+                    const float s1 = acc.x, sx = acc.y, sy = acc.z, v3 = acc.w;
                     const float dxq = __builtin_fmaf(bxq, s1, -sx), dyq = __builtin_fmaf(byq, s1, -sy);
                     const float t2q = __builtin_fmaf(mm_g == 0 ? bxq : byq, mm_g == 2u ? dyq : dxq,
                                                      __builtin_fmaf(-(mm_g == 2u ? byq : bxq), mm_g == 0 ? sx : sy, v3));
                     S1 += s1; Dx += dxq; Dy += dyq; t2 += t2q; Ay += sx; Az += sy;
+                };
+                if constexpr (MODE == 2) {
+                    float bq[4];   // (built here, a dozen operations per flagged batch, instead of held in four registers all along)
+                    mm_basis_subq4(bq, lane);
+                    shift_add(mm_contract_sq<0>(mrow, am, bq, lane, hit_blocks), bx + 2.f, by + 2.f);
+                    shift_add(mm_contract_sq<1>(mrow, am, bq, lane, hit_blocks), bx - 2.f, by + 2.f);
+                    shift_add(mm_contract_sq<2>(mrow, am, bq, lane, hit_blocks), bx + 2.f, by - 2.f);
+                    shift_add(mm_contract_sq<3>(mrow, am, bq, lane, hit_blocks), bx - 2.f, by - 2.f);
+                } else {
+                    f32x4 acc4[4];
+                    mm_contract4(mrow, am, lane, hit_blocks, acc4);
+                    shift_add(acc4[0], bx + 2.f, by + 2.f);
+                    shift_add(acc4[1], bx - 2.f, by + 2.f);
+                    shift_add(acc4[2], bx + 2.f, by - 2.f);
+                    shift_add(acc4[3], bx - 2.f, by - 2.f);
                 }
                 o1 = -0.5f * cO * t2;                                                        // conic x | y | w
                 o2 = (cO * mm_dd) * __builtin_fmaf(cP, Dx, cQ * Dy);                         // mean2D x | y
@@ -811,11 +880,12 @@ int debug_bwd_stats(unsigned long long* out8, int reset)
 static std::atomic<int> g_bwd_subq{-1};
 int backward_subquadrant_moments(int set)
 {
-    if (set >= 0) g_bwd_subq.store(set ? 1 : 0);
+    if (set >= 0) g_bwd_subq.store(set > 2 ? 2 : set);
     int v = g_bwd_subq.load();
     if (v < 0) {
         const char* e = getenv("GSR_BWD_SUBQ");
-        v = (e && atoi(e) != 0) ? 1 : 0;
+        v = e ? atoi(e) : GSR_BWD_SUBQ_DEFAULT;
+        v = v < 0 || v > 2 ? GSR_BWD_SUBQ_DEFAULT : v;
         g_bwd_subq.store(v);
     }
     return v;
@@ -852,13 +922,17 @@ int launch_render_backward(const Launch& L, const gsr_params& p, const Batch& B,
 #ifndef GSR_BWD_FILL
 #define GSR_BWD_FILL 4096
 #endif
-    a.dynamic = groups * B.V > GSR_BWD_FILL ? 1u : 0u;
+    // (batches only: a single view's 1 280 waves per XCD pulling from ONE counter wait for it -- 0.39 instead of 0.25 ms -- however
+    // many tiles the image has)
+    a.dynamic = (B.V > 1 && groups * B.V > GSR_BWD_FILL) ? 1u : 0u;
     if (a.dynamic) groups = div_up((int64_t)cus * 4 * 5 * 2, 32 * (int64_t)B.V);
     if (groups < 8) groups = 8;
-    if (backward_subquadrant_moments(-1))
-        hipLaunchKernelGGL(k_render_backward<true>, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
-    else
-        hipLaunchKernelGGL(k_render_backward<false>, dim3((unsigned)(groups * B.V) * 32u), dim3(64), 0, L.stream, a);
+    const dim3 grid((unsigned)(groups * B.V) * 32u);
+    switch (backward_subquadrant_moments(-1)) {
+    case 1: hipLaunchKernelGGL(k_render_backward<1>, grid, dim3(64), 0, L.stream, a); break;
+    case 2: hipLaunchKernelGGL(k_render_backward<2>, grid, dim3(64), 0, L.stream, a); break;
+    default: hipLaunchKernelGGL(k_render_backward<0>, grid, dim3(64), 0, L.stream, a); break;
+    }
     return check_launch(L, "render_backward");
 }
 

@@ -826,9 +826,10 @@ def selftest(device):
 
 
 def set_backward_moments(mode):
-    """0 (default): the render backward's pixel contraction takes second moments about the 8 x 8 quadrant centre; 1: about the four
-    4 x 4 sub-quadrant centres (mean2D / conic sums 1.25x / 1.9x the reference build's rounding error instead of 1.9x / 4x, for +8 %
-    of that kernel's time; include/gsr.h gsr_set_backward_moments, GSR_BWD_SUBQ).  Returns the mode in force."""
+    """How the render backward's pixel contraction takes its second moments: 0 about the quadrant centre, 1 about the four
+    sub-quadrant centres (mean2D / conic sums 1.25x / 2.0x the reference build's rounding error instead of 1.85x / 4.3x, +8 % of
+    that kernel's time), 2 (default) per batch of eight entries, the sub-quadrant way only where a splat lies far from the quadrant
+    centre in its own sigmas (1.33x / 2.1x, +0.8 %); include/gsr.h gsr_set_backward_moments, GSR_BWD_SUBQ.  Returns the mode in force."""
     return int(lib.gsr_set_backward_moments(int(mode)))
 
 

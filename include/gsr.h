@@ -252,10 +252,14 @@ int gsr_set_forward_half_views(int views);
  * GSR_SORT_LB_VIEWS), three-launch passes for larger batches.  mode < 0 / lookback_views < 0 leave the setting.  Returns the mode. */
 int gsr_set_sort_mode(int mode, int lookback_views);
 
-/* Accuracy / speed switch of the render backward's pixel contraction: 0 (default; GSR_BWD_SUBQ=0) second moments about the 8 x 8
- * quadrant centre; 1 about the centres of its four 4 x 4 sub-quadrants, each shifted to the splat centre on its own: the mean2D /
- * conic sums then carry the reference build's rounding error instead of 1.9x / 4x of it, for more arithmetic
- * per batch of eight entries.  mode < 0 only queries.  Returns the value in force. */
+/* Accuracy / speed switch of the render backward's pixel contraction (GSR_BWD_SUBQ in the environment): 0 second moments about the
+ * 8 x 8 quadrant centre, shifted to the splat centre per entry: the mean2D / conic sums carry 1.85x / 4.3x the reference build's own
+ * rounding error (median over 500 fuzz cases against a float64 evaluation of the same sums; two orders of magnitude inside every
+ * test bar); 1 about the centres of the four 4 x 4 sub-quadrants, each shifted on its own: 1.25x / 2.0x, +8 % kernel time;
+ * 2 (DEFAULT) adaptive: the sub-quadrant path only for batches of eight entries that hold a splat more than sqrt(20) of its own sigmas
+ * from the quadrant centre -- where that rounding comes from (sub-pixel splats seen from a quadrant away): 1.33x / 2.1x at +0.8 %
+ * kernel time on the benchmark views, none of whose batches takes it (profiles/r06_bwd_accuracy.txt).  mode < 0 only queries.
+ * Returns the value in force. */
 int gsr_set_backward_moments(int mode);
 
 const char* gsr_last_error(void);
