@@ -64,8 +64,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches (same guide)
 VALU_PEAK_GWIPS = 1228.9     # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
 
-STAGE_KERNEL = {"render_backward": "k_render_backward<false>", "render_forward": "k_render_forward<0>", "preprocess": "k_preprocess<1>",
-                "preprocess_backward": "k_preprocess_backward<1>", "duplicate": "k_duplicate<unsigned short>"}
+STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_render_forward", "preprocess": "k_preprocess<",
+                "preprocess_backward": "k_preprocess_backward", "duplicate": "k_duplicate"}
+
+
+def stage_kernel(stage, table):
+    """the profiled kernel of a stage: the entry of `table` (kernel name -> anything) whose name starts with the stage's kernel
+    prefix -- template arguments change between rounds and call shapes (k_render_backward<2>, k_render_forward_half)"""
+    pre = STAGE_KERNEL.get(stage, stage)
+    hits = [k for k in (table or {}) if k.startswith(pre)]
+    return hits[0] if len(hits) == 1 else (max(hits, key=lambda k: table[k] if isinstance(table[k], (int, float)) else 0) if hits else pre)
 
 
 GC_RECOVER_S = 0.15   # untimed load between the garbage collection and the first timed block (seconds)
@@ -179,6 +187,7 @@ def main():
                     help="fresh processes that each measure the drop-in figure on their own (min / median / max in the line: the "
                          "figure must not depend on how a process happened to set up its streams); 0 = skip")
     ap.add_argument("--drop-in-probe", action="store_true", help=argparse.SUPPRESS)   # what those processes run
+    ap.add_argument("--gather-probe", action="store_true", help=argparse.SUPPRESS)    # 1-rank RCCL anchor, run as a child under RANK=0 WORLD_SIZE=1
     ap.add_argument("--no-stage-events", action="store_true",
                     help="no per-stage hipEvents anywhere (for timeline traces: an event pair costs ~10 us of bubble per stage)")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
@@ -474,6 +483,30 @@ def main():
         return {"mean": round(float(d.mean()) * 1e6, 1), "median": round(float(np.median(d)) * 1e6, 1), "frames": int(d.size),
                 "what": "settings built -> gsr_forward_batch entered (the entry launches the first kernel at once), literal per-view loop"}
 
+    if args.gather_probe:
+        # World-size-1 anchor for the multi-GPU runs (nobody has measured more than one GPU yet): the same timed blocks with and
+        # without the RCCL gather of every submission's full-size frames on its side stream, in ONE process group of one rank.
+        # Alternating blocks; each block ends with the gather stream drained.
+        def block(gather_on):
+            fence()
+            t1 = time.perf_counter()
+            run_steps(0, args.steps, gather_on=gather_on)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        for _ in range(3):
+            block(True)
+        on, off = [], []
+        for _ in range(max(3, args.repeats)):
+            off.append(block(False))
+            on.append(block(True))
+        f_on, f_off = args.steps / float(np.median(on)), args.steps / float(np.median(off))
+        print(json.dumps({"frames_per_s_with_gather": round(f_on, 1), "frames_per_s_without": round(f_off, 1),
+                          "gather_overhead_pct": round(100.0 * (f_off / f_on - 1.0), 2), "backend": args.dist_backend,
+                          "mode": args.gather_mode, "frame_bytes": 3 * W * H * 4, "views_per_call": VPC, "world": world}))
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
     if args.drop_in_probe:
         # a fresh process measuring only the drop-in figure (spawned by the main run, --drop-in-processes)
         warm = 0
@@ -694,6 +727,28 @@ def main():
                                       "max": max(vals) if vals else None,
                                       "spread": round((max(vals) - min(vals)) / float(np.median(vals)), 4) if vals else None,
                                       "errors": errs or None}
+    gather_anchor = None
+    if world == 1 and not use_dist and not args.no_per_view and not args.no_gather:
+        # 1-rank anchor for the first multi-GPU run: a child process under RANK=0 WORLD_SIZE=1 (RCCL process group of one) times the
+        # same blocks with and without the frame gather on its side stream (--gather-probe above)
+        import socket
+        import subprocess
+        torch.cuda.synchronize()
+        try:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            cmdg = [sys.executable, os.path.abspath(__file__), "--gather-probe", "--gpus", "1", "--config", str(args.config), "--workload",
+                    args.workload, "--width", str(W), "--height", str(H), "--profile", args.profile, "--no-cpu-baseline", "--steps", "48",
+                    "--device-index", str(dev_index), "--gather-mode", args.gather_mode] + \
+                   (["--points", str(args.points)] if args.points else []) + (["--forward-only"] if args.forward_only else [])
+            r = subprocess.run(cmdg, capture_output=True, text=True, timeout=240, env=env)
+            ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            gather_anchor = json.loads(ls[-1]) if ls else {"error": (r.stdout + r.stderr)[-300:]}
+        except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
+            gather_anchor = {"error": repr(ex)}
     per_rank_blocks = None
     if use_dist:
         cdev = "cpu" if host_collectives else dev
@@ -766,7 +821,7 @@ def main():
             dom_ms = inreg_ms.get(dom, avg_ms[dom])
             dom_clk = float(np.median(sclk_timed)) if (dom in inreg_ms and sclk_timed) else (float(np.median(sclk_stage)) if sclk_stage else None)
             achieved = bytes_per[dom] * VPC / (dom_ms * 1e-3) / 1e9     # a launch covers VPC views
-            kname = STAGE_KERNEL.get(dom, dom)
+            kname = stage_kernel(dom, (pmc or {}).get("avg_us"))
             # `bound` names the roof `achieved` / `peak` / `frac` are quoted against (the contract: algorithmic HBM bytes over the
             # kernel's duration against the 8 TB/s peak); `binding_roof` names what actually limits the kernel
             render_dom = dom in ("render_backward", "render_forward")
@@ -814,8 +869,15 @@ def main():
                                         "note": "instructions per second against one plain wave64 instruction per SIMD per 2 cycles; "
                                                 "packed fp32 (4 cycles), transcendentals (8) and the backward's fp32 MFMAs (32) hold "
                                                 "their SIMD longer than that, so the SIMDs are busier than this fraction says"}
+                    roofline["issue_frac"] = roofline["valu"]["frac"]
+                vb = pmc.get("valu_busy", {}).get(kname)
+                if vb and vb.get("valu_busy") is not None:
+                    # what binds the render kernels, measured: the share of all SIMD cycles of the launch in which a vector (or
+                    # matrix) instruction executes -- counters of the profile lease; the live run only contributes the duration check
+                    roofline["valu_busy"] = dict(vb, source="profiles/pmc_traffic.json (lease %s, kernels_sha = this tree's)" % pmc.get("lease"),
+                                                 formula=pmc.get("valu_busy_formula"))
                     if render_dom:
-                        roofline["binding_frac"] = roofline["valu"]["frac"]
+                        roofline["binding_frac"] = vb["valu_busy"]
             else:
                 roofline["traffic_source"] = "null: " + pmc_why
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
@@ -939,6 +1001,9 @@ def main():
             "multi_gpu_status": "measured on %d GPU(s)" % world if (world > 1 and not host_collectives) else
                                 "no run on more than one GPU has been measured (one-GPU leases only): the N > 1 path is rehearsed with "
                                 "gloo ranks sharing one GPU (tests/test_gpu_bench.py) and 8 CPU ranks (tests/test_cpu_multiview.py)",
+            # world-size-1 anchor of the frame gather (a child process with a 1-rank RCCL group): frames/s with the gather of every
+            # submission's frames on its side stream vs without -- what the first measured 8-GPU run starts from
+            "gather_world1_anchor": gather_anchor,
             "kernels_ms": {k: round(v, 4) for k, v in avg_ms.items()},
             "kernel_timing": "hipEvents on the launch stream, single-stream pass right after the timed region",
             "views_per_call": VPC, "kernels_ms_per_frame": {k: round(v / VPC, 4) for k, v in avg_ms.items()},

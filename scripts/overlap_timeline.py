@@ -31,5 +31,8 @@ for s, e, n, q in rows:
 print("%-28s %6s %10s %10s" % ("kernel", "calls", "avg_us", "total_ms"))
 for n in sorted(dur, key=lambda n: -sum(dur[n]))[:14]:
     print("%-28s %6d %10.1f %10.2f" % (n[:28], len(dur[n]), sum(dur[n]) / len(dur[n]) / 1e3, sum(dur[n]) / 1e6))
-frames = len(dur.get("k_render_backward", [])) or len(dur.get("k_render_forward<0>", []))
+# (by prefix: the template arguments differ between rounds and call shapes -- k_render_backward<2>, k_render_forward_half)
+def launches(prefix):
+    return sum(len(v) for n, v in dur.items() if n.startswith(prefix))
+frames = launches("k_render_backward") or launches("k_render_forward")
 print("frames in window: %d -> %.3f ms/frame" % (frames, span / 1e6 / max(frames, 1)))

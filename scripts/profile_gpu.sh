@@ -3,7 +3,7 @@
 # command (FETCH_SIZE, WRITE_SIZE, SQ counters: never combined with trace domains) and the FETCH_SIZE calibration probe.
 # Results under gpurun_out/prof_<tag>/; scripts/update_profiles.py <tag> copies what is judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 EXTRA=${2:-}            # extra bench.py arguments, e.g. "--views-per-call 12"
 MODE=${3:-full}         # "trace": kernel-trace stats only (no PMC passes)
 OUT=$PWD/gpurun_out/prof_$TAG
@@ -16,7 +16,9 @@ BENCH="python $PWD/bench.py --steps 24 --warmup 3 --repeats 2 --no-cpu-baseline 
 if [ "$MODE" != "trace" ]; then
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/bench_pmc_fetch.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/bench_pmc_write.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/bench_pmc_sq.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/bench_pmc_sq.log 2>&1)
+# second SQ pass (8 slots per pass): what the VALU time is made of, and what the waves wait for (roofline.valu_busy, update_profiles.py)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/bench_pmc_sq2.log 2>&1)
 # what FETCH_SIZE / WRITE_SIZE mean for this library's access patterns, on this box
 mkdir -p $OUT/calib
 if [ ! -x scripts/probe/fetch_calib ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/probe/fetch_calib scripts/probe/fetch_calib.hip; fi

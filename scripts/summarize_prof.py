@@ -15,7 +15,7 @@ for f in stats:
     for r in rows[:24]:
         print("%-44s %8s %12.1f %12.2f %6.1f%%" % (short(r["Name"])[:44], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
                                                   float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         print("== %s: no counter_collection.csv ==" % tag); continue

@@ -6,7 +6,7 @@ usage: python scripts/update_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys, collections, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -47,7 +47,7 @@ if os.path.exists(cal):
             factor["_" + p[0]] = round(float(p[2]) / (float(p[3]) * 1024.0), 3)      # line bytes per counted byte
     if "_k_stream16" in factor:
         factor["default"] = factor["_k_stream16"]
-    for k in ("k_render_backward<false>", "k_render_backward<true>", "k_render_forward<0>", "k_render_forward_half"):
+    for k in ("k_render_backward<0>", "k_render_backward<1>", "k_render_backward<2>", "k_render_forward<0>", "k_render_forward_half"):
         if "_k_gather36" in factor:
             factor[k] = factor["_k_gather36"]
     if "_k_gather16" in factor:
@@ -102,19 +102,60 @@ out = {
     "avg_us": avg_us,
     "raw": {k: v for k, v in raw.items() if k.startswith("k_")},
 }
-sq = collections.defaultdict(lambda: collections.defaultdict(float)); sql = collections.defaultdict(set)
-for f in glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = short(r["Kernel_Name"])
-        if k.startswith("k_render"):
-            sq[k][r["Counter_Name"]] += float(r["Counter_Value"]); sql[k].add(r["Dispatch_Id"])
-out["valu_wave_instructions_per_launch"] = {k: int(v["SQ_INSTS_VALU"] / max(len(sql[k]), 1)) for k, v in sq.items() if "SQ_INSTS_VALU" in v}
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+for sub in ("pmc_sq", "pmc_sq2"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("k_render"):
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); launches[k].add(r["Dispatch_Id"])
+    for k in acc:
+        for c, v in acc[k].items():
+            if c == "GRBM_GUI_ACTIVE" and sub == "pmc_sq2" and "GRBM_GUI_ACTIVE" in sq[k]:
+                continue
+            sq[k][c] = v / max(len(launches[k]), 1)
+out["valu_wave_instructions_per_launch"] = {k: int(v["SQ_INSTS_VALU"]) for k, v in sq.items() if "SQ_INSTS_VALU" in v}
+# How busy the SIMDs are: SQ_ACTIVE_INST_VALU counts, summed over every SIMD of the chip, the QUAD-cycles a wave's
+# VALU instruction (matrix instructions included) occupies its SIMD (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles), so
+#   valu_busy = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles of the launch),  SIMDs = 256 CUs x 4,
+# with the launch's cycles from GRBM_GUI_ACTIVE of the same pass (summed over the 8 XCDs by the profiler: / 8; cross-checked against
+# duration x shader clock of the kernel trace).  1.0 = every SIMD executing a vector instruction in every cycle of the launch.
+N_SIMD, N_XCD = 1024, 8
+vb = {}
+for k, v in sq.items():
+    if "SQ_ACTIVE_INST_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
+        continue
+    cyc_trace = avg_us.get(k, 0.0) * (prof_clk or 0.0)       # us x MHz = cycles
+    # (whether the profiler reports the counter per XCD or summed over the eight is read off the trace's duration x clock)
+    div = N_XCD if not cyc_trace or abs(v["GRBM_GUI_ACTIVE"] / N_XCD - cyc_trace) < abs(v["GRBM_GUI_ACTIVE"] - cyc_trace) else 1
+    cyc = v["GRBM_GUI_ACTIVE"] / div
+    e = {"SQ_ACTIVE_INST_VALU_quad_cycles": int(v["SQ_ACTIVE_INST_VALU"]), "GRBM_GUI_ACTIVE": int(v["GRBM_GUI_ACTIVE"]),
+         "GRBM_GUI_ACTIVE_divided_by": div, "cycles_per_launch": int(cyc), "cycles_from_trace_duration_x_clock": int(cyc_trace) if cyc_trace else None,
+         "valu_busy": round(4.0 * v["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc), 4) if cyc else None}
+    if "SQ_WAVE_CYCLES" in v and v["SQ_WAVE_CYCLES"]:
+        # the same, per wave: share of a resident wave's life in which it executes vector instructions; x waves per SIMD = valu_busy
+        e["valu_share_of_wave_cycles"] = round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 4)
+        e["waves_resident_per_simd"] = round(4.0 * v["SQ_WAVE_CYCLES"] / (N_SIMD * cyc), 3) if cyc else None
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+              "SQ_WAIT_INST_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_LDS",
+              "SQ_LDS_BANK_CONFLICT", "SQ_WAVES"):
+        if c in v:
+            e[c] = int(v[c])
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and cyc:
+        e["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * cyc), 4)     # (cycles, per SIMD: the guide's unit note)
+    if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU"):
+        e["lanes_active_per_valu_cycle"] = round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 4.0), 2)
+    vb[k] = e
+out["valu_busy"] = vb
+out["valu_busy_formula"] = ("4 x SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), per launch, "
+                            "same PMC pass; profiles/%s_isa_mix.txt prices the same loops statically" % tag)
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 # the lease's own bench line could not know these counters yet (they were collected after it, minutes later on the same box):
 # complete its roofline block from them, and say so
 rf = bench.get("roofline")
 if rf:
-    kn = {"render_backward": "k_render_backward<false>", "render_forward": "k_render_forward<0>"}.get(rf["kernel"], rf["kernel"])
+    kn = next((k for k in sorted(avg_us, key=lambda k: -avg_us[k]) if k.startswith("k_" + rf["kernel"])), rf["kernel"])
     rf["traffic"] = out["bytes_per_launch"].get(kn)
     rf["traffic_source"] = ("filled in by scripts/update_profiles.py from the PMC passes of the SAME lease (profiles/pmc_traffic.json): "
                             "(%s x FETCH_SIZE + WRITE_SIZE) per launch" % factor.get(kn, factor["default"]))
@@ -133,8 +174,12 @@ if rf:
         rate = vi / (rf["avg_ms"] * 1e-3)
         rf["valu"] = {"wave_instructions": int(vi), "G_wave_instr_per_s": round(rate / 1e9, 1), "peak_G_wave_instr_per_s": 1228.9,
                       "frac": round(rate / 1e9 / 1228.9, 4), "source": "SQ_INSTS_VALU per launch (same lease); duration measured live"}
-        if "binding_frac" in rf and str(rf.get("binding_roof", "")).startswith("valu"):
-            rf["binding_frac"] = rf["valu"]["frac"]
+        rf["issue_frac"] = rf["valu"]["frac"]
+    b = vb.get(kn)
+    if b and b.get("valu_busy") is not None:
+        rf["valu_busy"] = dict(b, source="PMC passes of the same lease (profiles/pmc_traffic.json)", formula=out["valu_busy_formula"])
+        if str(rf.get("binding_roof", "")).startswith("valu"):
+            rf["binding_frac"] = b["valu_busy"]
     json.dump(bench, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
 # context figure: the reference's own kernels (oracle/_ref, hipify-perl build) on the same GPU and view, scripts/compare_ref.py
 cr = os.path.join(src, "compare_ref.json")
