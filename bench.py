@@ -58,103 +58,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-import hashlib  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
-HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches (same guide)
-VALU_PEAK_GWIPS = 1228.9     # 157.3 TFLOP/s fp32 vector spec / (64 lanes x 2 flop): wave64 instructions per second, in 1e9
-
-STAGE_KERNEL = {"render_backward": "k_render_backward", "render_forward": "k_render_forward", "preprocess": "k_preprocess<",
-                "preprocess_backward": "k_preprocess_backward", "duplicate": "k_duplicate"}
-
-
-def stage_kernel(stage, table):
-    """the profiled kernel of a stage: the entry of `table` (kernel name -> anything) whose name starts with the stage's kernel
-    prefix -- template arguments change between rounds and call shapes (k_render_backward<2>, k_render_forward_half)"""
-    pre = STAGE_KERNEL.get(stage, stage)
-    hits = [k for k in (table or {}) if k.startswith(pre)]
-    return hits[0] if len(hits) == 1 else (max(hits, key=lambda k: table[k] if isinstance(table[k], (int, float)) else 0) if hits else pre)
-
-
-GC_RECOVER_S = 0.15   # untimed load between the garbage collection and the first timed block (seconds)
-
-
-def kernels_sha():
-    """identity of the kernel sources this process runs (csrc/*.hip, *.hpp + include/gsr.h): counter profiles taken on other
-    kernels are not quoted (roofline.traffic is null then)"""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "gaussian-pcloud-render_amd", "csrc")
-    for f in sorted(os.listdir(d)) + ["../../include/gsr.h"]:
-        if f.endswith((".hip", ".hpp", ".h")):
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
-
-
-def algorithmic_bytes(P, V, R, T, N, K, C_fwd, C_bwd, tile_passes, views_per_call=1):
-    """Minimum HBM bytes each stage has to move PER FRAME when `views_per_call` views of one cloud travel in one submission.
-    Render / preprocess figures are SURVEY.md 8(d)'s per-view formulas with what a batched launch shares counted once per batch:
-    the per-Gaussian inputs of preprocess ((44 + 12 K) P) and of the per-Gaussian backward ((107 + 12 K) V) are read once for all
-    views, and the backward's outputs ((40 + 12 K) V) are written once (summed over the views in registers).  The sort figures
-    follow this library's own data flow (u32 depth keys and ids; tile keys are u16 for images of up to 65 536 tiles); the tile
-    ranges are found by binary search (about 24 two-byte probes per tile), not by a pass over the keys, and the prefix sum of the
-    tile counts is part of the pair emission (no separate scan).  R here is the number of pairs IN THE LISTS (`list_pairs_avg` of
-    the line: the reference's num_rendered minus the pairs footprint clipping leaves out, include/gsr.h reference_lists); C_fwd /
-    C_bwd are the list entries the render kernels consume, counted in those lists."""
-    b = {}
-    kb = 2 if T <= 65536 else 4
-    vpc = max(1, int(views_per_call))
-    b["preprocess"] = (44 + 12 * K) * P / vpc + 75 * V + 8 * (P - V)
-    b["depth_sort"] = 4 * (4 + 8 + 8) * P
-    b["duplicate"] = 20 * P + (kb + 4) * R
-    b["tile_sort"] = tile_passes * (kb + 2 * (kb + 4)) * R
-    b["tile_ranges"] = (24 * kb + 16) * T
-    b["render_forward"] = 40 * C_fwd + 8 * T + 20 * N
-    b["render_backward"] = 40 * C_bwd + 20 * N + 44 * V
-    b["preprocess_backward"] = 92 * V + ((107 + 12 * K) * V + (40 + 12 * K) * V) / vpc
-    return b
-
-
-# BASELINE.json configs this bench can run (`--config`); 2 is the headline
-CONFIGS = {
-    1: dict(workload="synth-THuman-256", width=1920, height=1080, forward_only=True, n_views=12, shard="circle",
-            what="configs[1]: THuman-256 (200K voxelised points), 1080p, forward-only"),
-    2: dict(workload="synth-THuman-800K", width=1920, height=1080, forward_only=False, n_views=12, shard="circle",
-            what="configs[2]: THuman-800K, 1080p, forward+backward (the headline)"),
-    3: dict(workload="synth-THuman-800K", width=1920, height=1080, forward_only=False, n_views=8, shard="views",
-            what="configs[3]: THuman-800K, 8 camera views sharded across the ranks, frames gathered on rank 0"),
-    4: dict(workload="synth-mesh-2M", width=3840, height=2160, forward_only=False, n_views=8, shard="views",
-            what="configs[4]: 2M-point sampled mesh, 3840x2160, forward+backward, 8 camera views sharded across the ranks"),
-}
-
-
-def view_of(k, rank, world, n_views, shard):
-    """Camera view of local step k on `rank`.
-    shard "circle" (weak scaling of the headline): every rank walks the whole circle, rank r starting (r n_views) // world views
-    in, so ANY n_views consecutive steps of a rank are n_views distinct views whatever the world size, and at a given step the
-    ranks render different views (world <= n_views).
-    shard "views" (configs[3] / [4]): the n_views views of one turn are dealt round-robin, rank r owns {v : v mod world == r}
-    (pcrender.multiview.shard_views) and walks its own views in order."""
-    if shard == "circle":
-        return (k + (rank * n_views) // world) % n_views
-    mine = list(range(rank, n_views, world)) or [rank % n_views]
-    return mine[k % len(mine)]
-
-
-def union_ms(intervals):
-    """total length of the union of (start, end) intervals"""
-    tot, cur_a, cur_b = 0.0, None, None
-    for a, b in sorted(intervals):
-        if cur_b is None or a > cur_b:
-            if cur_b is not None:
-                tot += cur_b - cur_a
-            cur_a, cur_b = a, b
-        else:
-            cur_b = max(cur_b, b)
-    if cur_b is not None:
-        tot += cur_b - cur_a
-    return tot
-
+from benchlib import cpu_baseline as _cpu_baseline, dist as _dist, roofline as _roofline  # noqa: E402
+from benchlib.roofline import HBM_ACHIEVABLE_GBS, HBM_PEAK_GBS, STAGE_KERNEL, VALU_PEAK_GWIPS, stage_kernel  # noqa: E402,F401
+from benchlib.timing import GC_RECOVER_S, union_ms  # noqa: E402,F401
+from benchlib.workload import CONFIGS, algorithmic_bytes, kernels_sha, view_of  # noqa: E402,F401
 
 def main():
     ap = argparse.ArgumentParser()
@@ -213,19 +120,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run
     if args.gpus > 1 and not launched:
-        # self-launch: one process per GPU over RCCL (the driver normally does this itself)
-        n_dev = torch.cuda.device_count()
-        if args.dist_backend == "nccl" and args.device_index < 0 and n_dev < args.gpus:
-            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; RCCL needs one device per rank "
-                             "(use --dist-backend gloo --device-index 0 to exercise the control flow on one GPU)" % (args.gpus, n_dev))
-        import socket
-        import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(_dist.self_launch(args, os.path.abspath(__file__), torch.cuda.device_count()))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -709,46 +604,12 @@ def main():
     if drop_in is not None and args.drop_in_processes > 0 and world == 1:
         # the drop-in figure from FRESH processes (each: import, build the cloud, one second of warm-up, three blocks of 48 frames):
         # it must not depend on what this process did before, nor on how a process's streams happened to be set up
-        import subprocess
         torch.cuda.synchronize()
-        cmdp = [sys.executable, os.path.abspath(__file__), "--drop-in-probe", "--config", str(args.config), "--workload", args.workload,
-                "--width", str(W), "--height", str(H), "--profile", args.profile, "--no-cpu-baseline"] + \
-               (["--points", str(args.points)] if args.points else []) + (["--forward-only"] if args.forward_only else [])
-        vals, errs = [], []
-        for _ in range(args.drop_in_processes):
-            try:
-                r = subprocess.run(cmdp, capture_output=True, text=True, timeout=300)
-                ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                vals.append(json.loads(ls[-1])["drop_in_frames_per_s"]) if ls else errs.append((r.stdout + r.stderr)[-200:])
-            except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
-                errs.append(repr(ex))
-        drop_in["fresh_processes"] = {"n": len(vals), "frames_per_s": vals,
-                                      "min": min(vals) if vals else None, "median": float(np.median(vals)) if vals else None,
-                                      "max": max(vals) if vals else None,
-                                      "spread": round((max(vals) - min(vals)) / float(np.median(vals)), 4) if vals else None,
-                                      "errors": errs or None}
+        drop_in["fresh_processes"] = _dist.drop_in_fresh_processes(args, os.path.abspath(__file__), W, H)
     gather_anchor = None
     if world == 1 and not use_dist and not args.no_per_view and not args.no_gather:
-        # 1-rank anchor for the first multi-GPU run: a child process under RANK=0 WORLD_SIZE=1 (RCCL process group of one) times the
-        # same blocks with and without the frame gather on its side stream (--gather-probe above)
-        import socket
-        import subprocess
         torch.cuda.synchronize()
-        try:
-            with socket.socket() as so:
-                so.bind(("127.0.0.1", 0))
-                port = so.getsockname()[1]
-            env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-            cmdg = [sys.executable, os.path.abspath(__file__), "--gather-probe", "--gpus", "1", "--config", str(args.config), "--workload",
-                    args.workload, "--width", str(W), "--height", str(H), "--profile", args.profile, "--no-cpu-baseline", "--steps", "48",
-                    "--device-index", str(dev_index), "--gather-mode", args.gather_mode] + \
-                   (["--points", str(args.points)] if args.points else []) + (["--forward-only"] if args.forward_only else [])
-            r = subprocess.run(cmdg, capture_output=True, text=True, timeout=240, env=env)
-            ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            gather_anchor = json.loads(ls[-1]) if ls else {"error": (r.stdout + r.stderr)[-300:]}
-        except Exception as ex:  # noqa: BLE001 -- a side figure must never take the headline down
-            gather_anchor = {"error": repr(ex)}
+        gather_anchor = _dist.gather_anchor(args, os.path.abspath(__file__), W, H, dev_index)
     per_rank_blocks = None
     if use_dist:
         cdev = "cpu" if host_collectives else dev
@@ -795,140 +656,11 @@ def main():
         tile_bits = int(T).bit_length()
         bytes_per = algorithmic_bytes(P, stats["V"], stats["L"], T, W * H, (D + 1) ** 2, stats["C_fwd"], stats["C_bwd"],
                                       (tile_bits + 7) // 8, views_per_call=VPC)
-        dom = max(avg_ms, key=avg_ms.get) if avg_ms else None
-        roofline = None
-        # HBM bytes / VALU instructions / kernel duration per launch from the committed rocprofv3 passes -- only if they were taken
-        # on THIS workload and call shape (scripts/profile_gpu.sh writes the key); anything else would be a number about
-        # another run
-        pmc, pmc_why = None, None
-        key = {"workload": args.workload, "points": P, "width": W, "height": H, "views_per_launch": VPC, "profile": args.profile,
-               "forward_only": bool(args.forward_only)}
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("key") != key:
-                pmc_why = "profiles/pmc_traffic.json was taken on %s, this run is %s" % (json.dumps(pmc.get("key")), json.dumps(key))
-                pmc = None
-            elif pmc.get("kernels_sha") != kernels_sha():
-                pmc_why = ("profiles/pmc_traffic.json was taken on other kernel sources (kernels_sha %s, lease %s; this tree is %s): "
-                           "its counters are not quoted for this run" % (pmc.get("kernels_sha"), pmc.get("lease"), kernels_sha()))
-                pmc = None
-        except (OSError, ValueError) as ex:
-            pmc_why = "profiles/pmc_traffic.json: %r" % (ex,)
-        if dom is not None:
-            # the dominant kernel's duration: hipEvents around it INSIDE the timed region when it is one of the render kernels
-            # (always, so far), else the per-stage pass
-            dom_ms = inreg_ms.get(dom, avg_ms[dom])
-            dom_clk = float(np.median(sclk_timed)) if (dom in inreg_ms and sclk_timed) else (float(np.median(sclk_stage)) if sclk_stage else None)
-            achieved = bytes_per[dom] * VPC / (dom_ms * 1e-3) / 1e9     # a launch covers VPC views
-            kname = stage_kernel(dom, (pmc or {}).get("avg_us"))
-            # `bound` names the roof `achieved` / `peak` / `frac` are quoted against (the contract: algorithmic HBM bytes over the
-            # kernel's duration against the 8 TB/s peak); `binding_roof` names what actually limits the kernel
-            render_dom = dom in ("render_backward", "render_forward")
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "binding_roof": "valu (fp32 vector + matrix issue on the SIMDs; see `valu`)" if render_dom else "hbm",
-                        "binding_frac": None,
-                        "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBS, 5),
-                        "algorithmic_bytes": int(bytes_per[dom] * VPC), "avg_ms": round(dom_ms, 4),
-                        "avg_ms_measured": "hipEvents on the launch stream around every launch of this kernel inside the timed region "
-                                           "(%d launches)" % len(inreg.get(dom, [])) if dom in inreg_ms else "per-stage pass after the timed region",
-                        "avg_ms_stage_pass": round(avg_ms[dom], 4),
-                        "views_per_launch": VPC,
-                        "note": "the render kernels are VALU-bound by two orders of magnitude of arithmetic intensity (SURVEY 8d): "
-                                "the fraction of the HBM roofline is structurally small; see `valu`"}
-            if pmc is not None:
-                roofline["traffic"] = pmc.get("bytes_per_launch", {}).get(kname)
-                roofline["traffic_source"] = ("builder lease %s (kernels_sha %s = this tree's): (FETCH_SIZE x %s + WRITE_SIZE) per launch, "
-                                              "rocprofv3 PMC passes of this command in the same lease as the kernel trace "
-                                              "(profiles/pmc_traffic.json; the FETCH factor is the one the lease's fetch calibration "
-                                              "measures for this kernel's access pattern)"
-                                              % (pmc.get("lease"), pmc.get("kernels_sha"),
-                                                 pmc.get("fetch_factor", {}).get(kname, pmc.get("fetch_factor", {}).get("default", 2))))
-                pa = pmc.get("avg_us", {}).get(kname)
-                if pa:
-                    roofline["profile_avg_ms"] = round(pa / 1e3, 4)
-                    roofline["frac_profile"] = round(bytes_per[dom] * VPC / (pa * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
-                    rel = dom_ms / (pa / 1e3)
-                    lv = {"ratio": round(rel, 3), "agree_within_10pct": bool(abs(rel - 1.0) <= 0.10)}
-                    # the same kernel on another box / in a profiled pass runs at another clock: compare CYCLES (ms x shader clock)
-                    pclk = pmc.get("sclk_mhz")
-                    if pclk and dom_clk:
-                        lclk = dom_clk
-                        reln = rel * lclk / float(pclk)
-                        lv.update({"sclk_mhz_live": round(lclk, 1), "sclk_mhz_profile": round(float(pclk), 1),
-                                   "ratio_clock_normalised": round(reln, 3),
-                                   "agree_within_10pct_clock_normalised": bool(abs(reln - 1.0) <= 0.10)})
-                    roofline["live_vs_profile"] = lv
-                valu = pmc.get("valu_wave_instructions_per_launch", {}).get(kname)
-                if valu:  # the render kernels are VALU-bound: wave64 fp32 issue rate against the 157.3 TFLOP/s vector spec
-                    rate = valu / (dom_ms * 1e-3)
-                    roofline["valu"] = {"wave_instructions": int(valu), "G_wave_instr_per_s": round(rate / 1e9, 1),
-                                        "peak_G_wave_instr_per_s": VALU_PEAK_GWIPS, "frac": round(rate / 1e9 / VALU_PEAK_GWIPS, 4),
-                                        "source": "SQ_INSTS_VALU per launch, profiles/pmc_traffic.json; duration measured live",
-                                        "note": "instructions per second against one plain wave64 instruction per SIMD per 2 cycles; "
-                                                "packed fp32 (4 cycles), transcendentals (8) and the backward's fp32 MFMAs (32) hold "
-                                                "their SIMD longer than that, so the SIMDs are busier than this fraction says"}
-                    roofline["issue_frac"] = roofline["valu"]["frac"]
-                vb = pmc.get("valu_busy", {}).get(kname)
-                if vb and vb.get("valu_busy") is not None:
-                    # what binds the render kernels, measured: the share of all SIMD cycles of the launch in which a vector (or
-                    # matrix) instruction executes -- counters of the profile lease; the live run only contributes the duration check
-                    roofline["valu_busy"] = dict(vb, source="profiles/pmc_traffic.json (lease %s, kernels_sha = this tree's)" % pmc.get("lease"),
-                                                 formula=pmc.get("valu_busy_formula"))
-                    if render_dom:
-                        roofline["binding_frac"] = vb["valu_busy"]
-            else:
-                roofline["traffic_source"] = "null: " + pmc_why
+        roofline = _roofline.build(avg_ms, inreg_ms, inreg, bytes_per, VPC, args, P, W, H, sclk_timed, sclk_stage)
         frame_bytes = sum(bytes_per[k] for k in bytes_per if (grad or "backward" not in k))
         frame_gpu_ms = sum(avg_ms.values()) / VPC if avg_ms else 0.0
 
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.oracle import Oracle, Scene
-            orc = Oracle()
-            v0 = views[0]
-            sc = Scene(W=W, H=H, tanfovx=v0["tanfovx"], tanfovy=v0["tanfovy"], bg=np.ones(3, np.float32), means3D=g["means3D"],
-                       opacities=g["opacities"], viewmatrix=v0["viewmatrix"].numpy(), projmatrix=v0["projmatrix"].numpy(),
-                       campos=v0["campos"].numpy(), shs=g["shs"], scales=g["scales"], rotations=g["rotations"], sh_degree=D)
-            cores = os.cpu_count() or 1
-            Gh = G.cpu().numpy()
-
-            def cpu_frame(nt):
-                t1 = time.perf_counter()
-                if grad:
-                    orc.forward_backward(sc, Gh, nthreads=nt)
-                else:
-                    orc.forward(sc, nthreads=nt)
-                return time.perf_counter() - t1
-
-            # os.cpu_count() is the machine, not what this container may use (a CPU quota makes 256 threads slower than 32):
-            # one probe frame at cores, cores/2, cores/4, cores/8 threads picks the thread count, which is what `cores` reports
-            host_cpus = cores
-            try:
-                host_cpus = min(cores, len(os.sched_getaffinity(0)))
-            except (AttributeError, OSError):
-                pass
-            probes = {}
-            for nt in sorted({max(1, host_cpus >> k) for k in range(4)}, reverse=True):
-                probes[nt] = cpu_frame(nt)
-            cores = min(probes, key=probes.get)
-            cpu_frame(cores)                                              # warm-up (page faults, thread pool)
-            times = sorted(cpu_frame(cores) for _ in range(max(1, args.cpu_frames)))
-            cdt = float(np.median(times))
-            what = "forward+backward" if grad else "forward"
-            cpu = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "circle view 0 of the same workload, %s, plain-C oracle with OpenMP (parallel per-Gaussian stages, "
-                             "parallel stable radix sort, per-thread gradient buffers): 1 warm-up + median of %d frames "
-                             "(min %.3f s, max %.3f s); thread count chosen by one probe frame each at %s threads (os.cpu_count() = %d)"
-                             % (what, len(times), times[0], times[-1], "/".join("%d: %.2f s" % (k, v) for k, v in probes.items()),
-                                os.cpu_count() or 1)}
-            if not args.no_cpu_1core:
-                c1 = cpu_frame(1)
-                cpu["one_core"] = {"value": round(1.0 / c1, 5), "unit": "frames/s", "cores": 1,
-                                   "sample": "1 frame of the same view, %s, single thread (no warm-up: %.1f s of CPU work)" % (what, c1)}
-                cpu["speedup_over_one_core"] = round(c1 / cdt, 2)
-
+        cpu = _cpu_baseline.measure(views, g, W, H, D, G, grad, args) if (world == 1 and not args.no_cpu_baseline) else None
         ref_ctx = None
         try:
             with open(os.path.join(ROOT, "profiles", "reference_build.json")) as f:

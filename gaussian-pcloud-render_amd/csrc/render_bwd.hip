@@ -21,11 +21,12 @@
 // batch (36 lanes each, the nine addresses of an entry inside one 64-B record, zero sums skipped) then update the
 // per-Gaussian gradient records: 9 atomics per (quadrant, entry) instead of 9 x 64.
 // Summation order differs from the reference's (undefined) atomic order and the second moments are shifted from the
-// quadrant centre to the splat centre after the sum; T / (1 - alpha) is the reference's division to the last bit but
-// rare boundary cases (v_rcp_f32 + one residual step).  Against the float64 value of the same sums
-// (oracle: orc_render_backward_fp64) the colour and opacity gradients are as accurate as the reference build's, the
-// mean2D / conic gradients 1.8x / 4x its error at the median (3e-7 .. 9e-7 of max|g|): the moments are rounded once per
-// quadrant where the reference rounds every pixel's product on its own (profiles/r04_bwd_accuracy.txt).
+// quadrant centre (or, for batches that hold a splat far from it in its own sigmas, from the four sub-quadrant centres: MODE 2,
+// the default) to the splat centre after the sum; T / (1 - alpha) is the reference's division to the last bit but rare boundary
+// cases (v_rcp_f32 + one residual step).  Against the float64 value of the same sums (oracle: orc_render_backward_fp64; 503 fuzz
+// cases, median of the max-element error) the colour and opacity gradients are as accurate as the reference build's (0.95x /
+// 1.06x), the mean2D / conic gradients carry 1.33x / 2.1x its error (3e-7 / 5e-7 of max|g|; 1.85x / 4.3x with the quadrant-centre
+// moments alone, 1.25x / 2.0x with the sub-quadrant ones everywhere): profiles/r06_bwd_accuracy.txt.
 #include <atomic>
 #include <cstdlib>
 
@@ -66,7 +67,11 @@ __device__ __forceinline__ void bw_prefetch4f(float& dst, const void* p)
 // group, component-major inside the group: x0..x3 | y0..y3 | A | B | C | opacity | r | g | b | id  (10 x 16 B), so one
 // same-address ds_read_b128 per component hands every lane the four entries' values, pairs adjacent for the
 // packed fp32 instructions.
-constexpr int QUAD_WORDS = 40;
+// Groups are 44 words apart, not 40: a round's survivors are staged by slot, lane s writing word (s & 3) of group s >> 2, and with a
+// stride of 40 words the sixteen groups start on only four different banks (8 g mod 32): every one of the ten staging stores of a
+// round was a 4-way bank conflict -- all of the kernel's SQ_LDS_BANK_CONFLICT cycles (5.4e7 per 12-view launch, profiles/r06_*).
+// 44 puts the first eight groups on eight different bank quads (12 g mod 32): 2 lanes per bank, the minimum for 64 lanes.
+constexpr int QUAD_WORDS = 44;
 
 // core of ocml expf without its range clamps; bit-identical to expf on [-103, 0] (see render_fwd.hip)
 __device__ __forceinline__ float bw_exp_nonpos(float x)
@@ -372,8 +377,9 @@ struct RenderBwdArgs {
     size_t g_stride, b_stride, iv_stride, gr_stride;
 };
 
-// five waves per SIMD: 96 registers (the accumulator in VGPRs, five values of the item set-up spilled outside the hot
-// loops); the loop runs at ~70 % of the vector pipe with four waves, a fifth is worth 2.6 %
+// five waves per SIMD: 96 registers, the accumulators in VGPRs.  MODE 0 fits without scratch; in MODE 2 the cold sub-quadrant path
+// spills inside itself (and eight lane constants once per wave at kernel start, reloaded only there): the hot loops and the item
+// set-up are free of scratch accesses (checked in the assembly, profiles/r06_isa_mix.txt).  A fifth wave per SIMD is worth 2.6 %.
 // MODE: 0 moments about the quadrant centre; 1 about the four sub-quadrant centres; 2 ADAPTIVE: per batch of eight entries, the
 // sub-quadrant path only when one of them is flagged -- (b / sigma)^2 > SUBQ_M, b = splat centre - quadrant centre measured with the
 // splat's own conic (one compare when the entry is staged; the flag rides in bit 31 of the staged id).  The float32 rounding of
