@@ -153,7 +153,7 @@ static std::atomic<long long> g_d2h_count{0};
 // ---- which way the sorts run (common.hpp sort_mode) ------------------------------------------------------------------------------
 static std::atomic<int> g_sort_mode{[] { const char* e = getenv("GSR_SORT_MODE"); const int m = e ? atoi(e) : 0; return m < 0 || m > 2 ? 0 : m; }()};
 static std::atomic<int> g_sort_lb_views{[] { const char* e = getenv("GSR_SORT_LB_VIEWS"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }()};
-static std::atomic<int> g_tickets{[] { const char* e = getenv("GSR_TICKETS"); return e && atoi(e) != 0 ? 1 : 0; }()};
+static std::atomic<int> g_tickets{[] { const char* e = getenv("GSR_TICKETS"); return e && atoi(e) == 0 ? 0 : 1; }()};
 int block_tickets(int set)
 {
     if (set >= 0) g_tickets = set != 0;

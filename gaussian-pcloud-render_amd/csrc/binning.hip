@@ -90,8 +90,9 @@ __global__ __launch_bounds__(DUP_THREADS) void k_duplicate(DupArgs a)
     const uint32_t view = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t* status = at_view(a.dup_status, a.g_stride, view);
-    // Which DUP_BLOCK Gaussians this workgroup takes: its blockIdx, or (a.tickets) a ticket drawn when it STARTS -- the look-back
-    // below only ever waits for lower-numbered workgroups (common.hpp block_tickets: why that ends, and what the tickets cost).
+    // Which DUP_BLOCK Gaussians this workgroup takes is decided by a ticket drawn when it STARTS (a.tickets, the default): a workgroup
+    // with a lower number has started earlier, so the look-back below only ever waits for workgroups that are already running or
+    // done, whatever order the hardware dispatches blockIdx in.  (a.tickets == 0: by blockIdx, common.hpp block_tickets.)
     // The ticket word follows the status words.
     const uint32_t nblk = gridDim.x;
     DUP_T(t0);

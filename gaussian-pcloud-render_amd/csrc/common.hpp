@@ -367,13 +367,14 @@ int launch_tile_sort_lookback(const Launch& L, const SortJob& job, const LbJob& 
 // which way the sorts of a submission run: 0 three launches per pass, 1 look-back passes, 2 (default) look-back for submissions of up
 // to lookback_max_views() views.  set < 0 only queries.  (api.hip; GSR_SORT_MODE / GSR_SORT_LB_VIEWS in the environment)
 // How the kernels whose workgroups wait for lower-numbered workgroups of the same launch (pair emission, look-back scatter) number
-// themselves.  0 (default): by blockIdx.  The hardware hands the workgroups of a launch to each XCD in increasing order (workgroup i
-// goes to XCD i mod 8, each XCD takes its share in order), so the lowest-numbered unfinished workgroup is always resident or next in
-// line on its XCD, it waits for nothing that is unfinished, and by induction every wait ends; a lower-numbered workgroup that is not
-// yet resident only delays its waiters until a slot frees up.  1 (GSR_TICKETS=1): by a ticket drawn with an atomic when the workgroup
-// starts -- independent of any dispatch order, but every workgroup of the launch then hits ONE address, and same-address atomics from
-// eight XCDs complete at about one per 70 ns: 1 800 scatter workgroups spent 180 us queueing for tickets in a pass that takes 20
-// (gpurun_out/r6b), the emission's 782 workgroups 50 us.  Every wait is bounded either way (CNT_STALL).
+// themselves.  1 (default): by a ticket drawn with an atomic when the workgroup STARTS -- a lower number has started earlier, so the
+// waits below can only be for workgroups that are running or done, whatever order the hardware dispatches blockIdx in (HIP promises
+// none; rocPRIM's look-back scans draw tickets for the same reason).  The price: every workgroup of a launch hits ONE address, and
+// same-address atomics from eight XCDs complete at about one per 13-70 ns: 10 us of a single view's 52-us emission.
+// 0 (GSR_TICKETS=0, opt-in): by blockIdx -- correct as long as the hardware hands the workgroups of a launch to each XCD in
+// increasing order (it does today: workgroup i goes to XCD i mod 8, each XCD takes its share in order; the lowest-numbered unfinished
+// workgroup is then always resident or next in line, waits for nothing unfinished, and by induction every wait ends), which is an
+// observation about this part, not a contract.  Every wait is bounded either way (CNT_STALL: the frame fails, it does not hang).
 int block_tickets(int set);
 int sort_mode(int set);
 int lookback_max_views(int set);

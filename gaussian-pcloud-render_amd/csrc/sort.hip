@@ -273,7 +273,8 @@ __device__ __forceinline__ uint32_t lb_wait(const uint32_t* p, uint32_t v, const
 // ---- pass kernel 3: stable scatter ----------------------------------------------------------------
 // LB = false: the block's per-digit offsets come from the count matrix the row scan left (hist / totals).
 // LB = true : no count matrix -- blocks publish their digit counts and sum what the blocks before them published (two-level,
-//             flat: see common.hpp).  A block only ever waits for lower-numbered blocks (common.hpp block_tickets: why that ends).
+//             flat: see common.hpp).  A block only ever waits for lower-numbered blocks, numbered by a ticket drawn at their start
+//             (or by blockIdx: common.hpp block_tickets).
 template <int BITS, typename KeyT, int RS_ITEMS, bool LB>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const KeyT* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,  // NULL: value = index

@@ -211,7 +211,7 @@ def test_half_quadrant_forward_equals_the_8x8_kernel(name, gpu_device):
         b, gb = run_product(s, gpu_device, dL_dpix=dL)
     finally:
         N.lib.gsr_set_forward_half_views(was)
-    for k in ("out_color", "final_T", "n_contrib", "radii", "vals", "ranges"):
+    for k in ("out_color", "final_T", "n_contrib", "radii", "vals", "ranges", "tile_need"):
         assert a[k].tobytes() == b[k].tobytes(), k
     r = _ref("strict").forward(s)
     assert b["out_color"].tobytes() == r["out_color"].tobytes() and b["final_T"].tobytes() == r["final_T"].tobytes()

@@ -251,6 +251,7 @@ def _run_product(scene, device, dL_dpix, debug, need_backward, light):
         out["depth_sort"] = q("DEPTH_SORT").view(np.uint32)   # key base, key bits compared, passes run
         if nb:
             out["clamped"] = q("CLAMPED")
+            out["tile_need"] = q("TILE_NEED").view(np.uint32)   # list entries each tile's forward walked: what the backward's items are cut from
         out["visible"] = int((out["radii"] > 0).sum())
     grads = None
     if dL_dpix is not None:
