@@ -69,8 +69,9 @@ __device__ __forceinline__ void bw_prefetch4f(float& dst, const void* p)
 // packed fp32 instructions.
 // Groups are 44 words apart, not 40: a round's survivors are staged by slot, lane s writing word (s & 3) of group s >> 2, and with a
 // stride of 40 words the sixteen groups start on only four different banks (8 g mod 32): every one of the ten staging stores of a
-// round was a 4-way bank conflict -- all of the kernel's SQ_LDS_BANK_CONFLICT cycles (5.4e7 per 12-view launch, profiles/r06_*).
-// 44 puts the first eight groups on eight different bank quads (12 g mod 32): 2 lanes per bank, the minimum for 64 lanes.
+// round was a 4-way bank conflict.  44 puts the first eight groups on eight different bank quads (12 g mod 32): 2 lanes per bank, the
+// minimum for 64 lanes.  Measured: SQ_LDS_BANK_CONFLICT 5.35e7 -> 4.67e7 per 12-view launch (-13 %), kernel time unchanged -- the
+// conflicts are not what the kernel waits for (profiles/r06_bench_rocprofv3_summary.txt).
 constexpr int QUAD_WORDS = 44;
 
 // core of ocml expf without its range clamps; bit-identical to expf on [-103, 0] (see render_fwd.hip)
