@@ -513,7 +513,13 @@ int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t ge
 {
     if (nx != 4 && nx != 8) return fail(GSR_ERR_INVALID, "[gsr] extra channels come in 4 or 8 (got %d): pad with zeros", nx);
     if (!extra || !bg_extra || !out_extra) return fail(GSR_ERR_INVALID, "[gsr] an extra-channel pointer is NULL");
-    const ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra, extra_per_view ? (size_t)p->P * (size_t)nx : (size_t)0};
+    if (extra_per_view < 0 || extra_per_view > 2 || (extra_per_view == 2 && nx != 8))
+        return fail(GSR_ERR_INVALID, "[gsr] extra_per_view is 0, 1 or (with 8 channels) 2");
+    ExtraChannels X{nx, extra, extra_view_scale, bg_extra, out_extra, extra_per_view == 1 ? (size_t)p->P * (size_t)nx : (size_t)0};
+    if (extra_per_view == 2) {   // [P][4] shared by the views, then [V][P][4]
+        X.values_hi = extra + (size_t)p->P * 4;
+        X.hi_view_stride = (size_t)p->P * 4;
+    }
     return forward_impl(p, V, geom, geom_bytes, image, image_bytes, binning, binning_bytes, radii, out_color, num_rendered,
                         resume ? 1 : 0, (hipStream_t)stream, &X);
 }

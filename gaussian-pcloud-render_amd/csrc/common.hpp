@@ -395,6 +395,8 @@ struct ExtraChannels {
     const float* bg;          // [nx]
     float* out;               // [V][nx][H][W]
     size_t view_stride;       // floats between consecutive views' value arrays (0: one array shared by the views)
+    const float* values_hi = nullptr;   // nx = 8, split layout: channels 4..7 as [V][P][4], channels 0..3 in `values` as [P][4] shared
+    size_t hi_view_stride = 0;
 };
 int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, const uint32_t* point_list, float* out_color,
                           bool with_ckpt, const ExtraChannels* X = nullptr);

@@ -53,6 +53,9 @@ struct RenderArgs {
     // extra channels (k_render_forward<NX>, NX > 0): composited with the same alphas as the colour
     const float* extra;        // [P][NX] per-Gaussian values, shared by the views (extra_vstride = 0) or one array per view
     size_t extra_vstride;      // floats between consecutive views' arrays
+    size_t extra_hi_vstride;
+    const float* extra_hi;     // NX = 8, split layout: channels 4..7 as [V][P][4] (channels 0..3 then come from `extra` as [P][4],
+                               // shared by the views); NULL: all NX channels interleaved in `extra`
     const float* extra_scale;  // [V][NX] per-view factors applied to them (NULL: 1), e.g. the +-1 of view-dependent normals
     const float* bg_extra;     // [NX]
     float* out_extra;          // [V][NX][H][W]
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
     a.splat = at_view(a.splat, a.g_stride, view);
     a.out_color += (size_t)view * 3u * (size_t)a.W * (size_t)a.H;
     if (NX > 0) a.extra += (size_t)view * a.extra_vstride;
+    // split layout: a Gaussian's first quad is extra[4 id], its second extra_hi[4 (view P + id)] (both 16-B records)
+    const bool x_split = NX > 4 && a.extra_hi != nullptr;
+    const float* const x_hi = x_split ? a.extra_hi + (size_t)view * a.extra_hi_vstride : a.extra + 4;
+    const uint32_t x_nx = x_split ? 4u : (uint32_t)NX;
     const uint32_t tile = a.tile_order[order_slot];
     const uint32_t q = (blockIdx.x >> 3) & 3u;
     const uint32_t lane = threadIdx.x;
@@ -313,9 +320,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
             prefetch16(c1, &sp->q1);
             prefetch4f(c2b, &sp->q2);
             if (NX > 0) {
-                const float* xp = a.extra + (size_t)id_cur * NX;
-                prefetch16(cx0, xp);
-                if (NX > 4) prefetch16(cx1, xp + 4);
+                prefetch16(cx0, a.extra + (size_t)id_cur * x_nx);
+                if (NX > 4) prefetch16(cx1, x_hi + (size_t)id_cur * x_nx);
                 retire_prefetch_x(c0, c1, c2b, id_nxt, cx0, cx1);
             } else {
                 retire_prefetch(c0, c1, c2b, id_nxt);
@@ -328,9 +334,8 @@ __global__ __launch_bounds__(64) void k_render_forward(RenderArgs a)
                 prefetch16(n1, &sp->q1);
                 prefetch4f(n2b, &sp->q2);
                 if (NX > 0) {
-                    const float* xp = a.extra + (size_t)id_nxt * NX;
-                    prefetch16(nx0, xp);
-                    if (NX > 4) prefetch16(nx1, xp + 4);
+                    prefetch16(nx0, a.extra + (size_t)id_nxt * x_nx);
+                    if (NX > 4) prefetch16(nx1, x_hi + (size_t)id_nxt * x_nx);
                 }
                 const int i2 = base + 128 + (int)lane;
                 prefetch4(id_nn, plist + (i2 < total ? i2 : last));
@@ -857,9 +862,11 @@ int launch_render_forward(const Launch& L, const gsr_params& p, const Batch& B, 
     a.chunk_shift = B.chunk_shift();
     // tile_need was cleared at the start of the frame (k_preprocess; the host on a retry / re-render)
     a.extra = nullptr; a.extra_scale = nullptr; a.bg_extra = nullptr; a.out_extra = nullptr; a.extra_vstride = 0;
+    a.extra_hi = nullptr; a.extra_hi_vstride = 0;
     const dim3 grid((unsigned)div_up(T, 8) * 32u * (unsigned)B.V);
     if (X != nullptr && X->nx > 0) {
         a.extra = X->values; a.extra_scale = X->view_scale; a.bg_extra = X->bg; a.out_extra = X->out; a.extra_vstride = X->view_stride;
+        a.extra_hi = X->values_hi; a.extra_hi_vstride = X->hi_view_stride;
         if (X->nx == 4) hipLaunchKernelGGL(k_render_forward<4>, grid, dim3(64), 0, L.stream, a);
         else hipLaunchKernelGGL(k_render_forward<8>, grid, dim3(64), 0, L.stream, a);
     } else if (B.V <= forward_half_views(-1)) {

@@ -411,7 +411,8 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     """V views of one cloud in one submission (C ABI gsr_forward_batch): viewmatrices / projmatrices [V,4,4] (transposed like
     the reference's settings), camposs [V,3].  Returns (num_rendered list[V], out_color [V,3,H,W], radii [V,P],
     geomBuffer, binningBuffer, imgBuffer).  `capacity` (pairs per view) overrides the remembered arena capacity.
-    extra = (values [P,nx] shared by the views or [V,P,nx] per view, view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the
+    extra = (values [P,nx] shared by the views or [V,P,nx] per view -- or the pair ([P,4] shared, [V,P,4] per view) for eight channels
+    of which only the last four depend on the view --, view_scale [V,nx] or None, bg [nx]) with nx in (4, 8): the
     render also composites those channels with the colour's alphas (gsr_forward_batch_channels) and the result gains a 7th
     element, out_extra [V,nx,H,W]."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -427,10 +428,18 @@ def rasterize_gaussians_batch(background, means3D, colors, opacity, scales, rota
     xv = xs = xb = None
     if extra is not None:
         xv, xs, xb = extra
-        x_per_view = int(xv.dim() == 3)
-        nx = int(xv.shape[-1]) if xv.dim() in (2, 3) else -1
-        if nx not in (4, 8) or xv.shape[-2] != P or (x_per_view and xv.shape[0] != V):
-            raise RuntimeError("extra channels must have shape (num_points, 4 or 8) or (num_views, num_points, 4 or 8)")
+        if isinstance(xv, (tuple, list)):
+            # split layout (gsr.h extra_per_view = 2): channels 0..3 shared by the views [P,4], channels 4..7 per view [V,P,4]
+            lo, hi = xv
+            if tuple(lo.shape) != (P, 4) or tuple(hi.shape) != (V, P, 4):
+                raise RuntimeError("split extra channels must have shapes (num_points, 4) and (num_views, num_points, 4)")
+            xv = torch.cat([_f32c(lo, device, "extra").reshape(-1), _f32c(hi, device, "extra").reshape(-1)])
+            x_per_view, nx = 2, 8
+        else:
+            x_per_view = int(xv.dim() == 3)
+            nx = int(xv.shape[-1]) if xv.dim() in (2, 3) else -1
+            if nx not in (4, 8) or xv.shape[-2] != P or (x_per_view and xv.shape[0] != V):
+                raise RuntimeError("extra channels must have shape (num_points, 4 or 8) or (num_views, num_points, 4 or 8)")
         if xb.numel() != nx or (xs is not None and tuple(xs.shape) != (V, nx)):
             raise RuntimeError("bg_extra must have nx entries and view_scale shape (V, nx)")
     if P == 0:  # rasterize_points.cu:81: the zero image (not the background) is returned

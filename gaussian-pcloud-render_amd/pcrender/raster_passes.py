@@ -188,12 +188,13 @@ def render_passes(means3D, opacities, scales, rotations, shs, H_c2w, h, w, fov, 
         # of the colour render (gsr_forward_batch_channels) -- same alphas, same stopping decisions, the same sums term for term
         P = means3D.shape[0]
         one = torch.ones((P, 1), dtype=torch.float32, device=device)
-        if nv is None:
-            extra = torch.cat([means3D, one], dim=1).contiguous()                                           # [P, 4], shared by the views
-        else:
-            extra = torch.cat([means3D.unsqueeze(0).expand(num_q, P, 3), one.unsqueeze(0).expand(num_q, P, 1), nv,
-                               torch.zeros((num_q, P, 1), dtype=torch.float32, device=device)], dim=2).contiguous()   # [q, P, 8]
-        nx = extra.shape[-1]
+        extra = torch.cat([means3D, one], dim=1).contiguous()                                               # [P, 4], shared by the views
+        nx = 4
+        if nv is not None:
+            # + the turned normals, one [P, 4] array per view; xyz and the hit value stay shared (split layout: 16 B per point
+            # + 16 B per point and view instead of 32 B per point and view)
+            extra = (extra, torch.cat([nv, torch.zeros((num_q, P, 1), dtype=torch.float32, device=device)], dim=2).contiguous())
+            nx = 8
         counts, rgb, radii, geom, binning, img, ex = _native.rasterize_gaussians_batch(
             bg_d, means3D, e, opacities, sc, rotations, 1.0, e, view, proj, a["tanfovx"], a["tanfovy"], H, W, shs, sh_degree, cam,
             False, False, need_backward=False, extra=(extra, None, bg_d[0:1].expand(nx)))

@@ -128,7 +128,8 @@ int gsr_forward_batch(const gsr_params* p, int V, void* geom, size_t geom_bytes,
  * reference's callers render world xyz, a hit map and normals that way, one full rasterizer call each
  * (simple_raw_render.py:410-524), recomputing identical alphas four times.  extra_per_view = 0: extra [P][nx] is shared by the
  * views; 1: extra [V][P][nx], one array per view (the reference turns every normal towards the camera of the view it renders,
- * simple_raw_render.py:264-268).  extra_view_scale [V][nx] (or NULL) multiplies the values per view and channel.
+ * simple_raw_render.py:264-268); 2 (nx = 8 only): split -- extra holds channels 0..3 as [P][4] shared by the views, followed by
+ * channels 4..7 as [V][P][4] (world xyz + hit value once, the turned normals per view: half the memory of 1 for that use).  extra_view_scale [V][nx] (or NULL) multiplies the values per view and channel.
  * out_extra is [V][nx][H][W].  P == 0: nothing is written (like out_color).  Same GSR_RETRY / resume contract. */
 int gsr_forward_batch_channels(const gsr_params* p, int V, void* geom, size_t geom_bytes, void* image, size_t image_bytes,
                                void* binning, size_t binning_bytes, int* radii, float* out_color, int64_t* num_rendered, int resume,

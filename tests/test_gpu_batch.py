@@ -276,6 +276,30 @@ def test_extra_channels_equal_separate_colour_passes(gpu_device, nx, V, need_bac
             assert torch.equal(out_x[v, ks], ref), (k0, v)
 
 
+def test_split_extra_channels_equal_the_per_view_layout(gpu_device):
+    """extra_per_view = 2 (include/gsr.h): channels 0..3 as one [P,4] array shared by the views, channels 4..7 as [V,P,4] -- half the
+    memory of a [V,P,8] array when only the last four depend on the view (world xyz + hit value vs the normals turned per view).
+    Bit for bit the result of the interleaved per-view layout, and the colour output is the plain call's."""
+    from diff_gaussian_rasterization import _native as N
+    dev = gpu_device
+    V = 3
+    g, views, W, H = _views_scene(V)
+    args = _batch_args(g, views, W, H, dev, bg=(0.5, 0.5, 0.5))
+    P = g["means3D"].shape[0]
+    rng = np.random.default_rng(47)
+    lo = _t(rng.normal(0, 1, (P, 4)).astype(np.float32), dev)
+    hi = _t(rng.normal(0, 1, (V, P, 4)).astype(np.float32), dev)
+    bgx = _t(rng.uniform(0, 1, 8).astype(np.float32), dev)
+    scale = _t(rng.choice([-1.0, 1.0, 0.5], (V, 8)).astype(np.float32), dev)
+    full = torch.cat([lo.unsqueeze(0).expand(V, P, 4), hi], dim=2).contiguous()
+    a = N.rasterize_gaussians_batch(*args, need_backward=False, extra=(full, scale, bgx))
+    b = N.rasterize_gaussians_batch(*args, need_backward=False, extra=((lo, hi), scale, bgx))
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert b[6].shape == (V, 8, H, W) and torch.equal(a[6], b[6])
+    with pytest.raises(RuntimeError, match="split extra channels"):
+        N.rasterize_gaussians_batch(*args, need_backward=False, extra=((lo, hi[:2]), scale, bgx))
+
+
 def test_extra_channels_argument_checks(gpu_device):
     from diff_gaussian_rasterization import _native as N
     dev = gpu_device
