@@ -276,3 +276,53 @@ def test_float_aligned_gradient_outputs_take_the_scalar_store_path(gpu_device):
             bargs[0], bargs[1], radii.reshape(1, -1), bargs[3], bargs[4], bargs[5], bargs[6], bargs[7], bargs[8].reshape(1, 4, 4),
             bargs[9].reshape(1, 4, 4), bargs[10], bargs[11], bargs[12].reshape(1, 3, s.H, s.W), bargs[13], bargs[14],
             bargs[15].reshape(1, 3), geom, binning, img, False, _alloc=all_shifted)
+
+
+def test_short_host_path_equals_the_general_path_and_survives_a_grown_frame(gpu_device):
+    """Steady-state per-view calls take _native.forward_view / backward_view (one arena allocation, inline checks: the host time
+    between the caller's last copy and the first kernel).  Same images, radii and gradients as the general path (debug=True settings
+    never take the short one); a frame that suddenly needs more pairs than the remembered capacity repeats its binning half on a
+    larger arena (GSR_RETRY inside the short path) and still renders the right image."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _native as N
+    import diff_gaussian_rasterization as d
+    dev = gpu_device
+    s = build_scene("capsule_circle")
+    dL = torch.from_numpy(seeded_dL(s)).to(dev)
+    taken = []
+    real = N.forward_view
+
+    def spy(*a, **k):
+        r = real(*a, **k)
+        taken.append(r is not None)
+        return r
+
+    def run(scales_factor, debug):
+        L = dict(means3D=_leaf(s.means3D, dev), shs=_leaf(s.shs, dev), opacities=_leaf(s.opacities.reshape(-1, 1), dev),
+                 scales=_leaf(s.scales * scales_factor, dev), rotations=_leaf(s.rotations, dev))
+        L["means2D"] = torch.zeros_like(L["means3D"], requires_grad=True)
+        img, radii = GaussianRasterizer(_settings(s, dev, debug=debug))(**L)
+        (img * dL).sum().backward()
+        return img.detach(), radii, {k: v.grad for k, v in L.items()}
+
+    N.forward_view = spy
+    try:
+        N.reset_capacity_hints()
+        run(1.0, False)                        # first frame of the configuration: counts synchronously (general path)
+        a = run(1.0, False)                    # steady state: the short path
+        assert taken[-2:] == [False, True]
+        b = run(1.0, True)                     # debug settings: the general path
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for k in a[2]:
+            ga, gb = a[2][k], b[2][k]
+            assert (ga - gb).abs().max() <= 2e-4 * gb.abs().max() + 1e-30, k          # (atomic order)
+        # three times the scales: ~9x the pairs, far beyond capacity hint x 1.25 -> the short path retries
+        hint = N._CAP_HINT[N._cap_key(dev, s.P, s.W, s.H)]
+        c = run(3.0, False)
+        assert taken[-1] is True and N._CAP_HINT[N._cap_key(dev, s.P, s.W, s.H)] > 2 * hint
+        e = run(3.0, True)
+        assert torch.equal(c[0], e[0]) and torch.equal(c[1], e[1])
+        for k in c[2]:
+            assert (c[2][k] - e[2][k]).abs().max() <= 2e-4 * e[2][k].abs().max() + 1e-30, k
+    finally:
+        N.forward_view = real
+    assert d._C.forward_view is real
